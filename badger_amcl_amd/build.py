@@ -1,0 +1,40 @@
+"""Builds libbadger_pf_hip.so (gfx950) in-tree with hipcc.  No CPU fallback exists."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "engine.hip")
+OUT = os.path.join(HERE, "libbadger_pf_hip.so")
+DEPS = [os.path.join(HERE, "csrc", f) for f in
+        ("engine.hip", "device_types.hpp", "kernels_score.hpp", "kernels_pf.hpp", "kernels_cloud.hpp",
+         "kdhist.hpp")] + [os.path.join(os.path.dirname(HERE), "include", "badger_pf.h")]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP engine cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,73 @@
+// Device-visible plain structs shared by the kernels and the host engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bpf
+{
+
+// 2-D map as it lives in HBM.
+//  * lut_tiles: the distance LUT re-encoded as 16-bit level indices in 8x8-cell tiles
+//    (one tile = 128 B = one cache line), so that beam end points that are close in
+//    EITHER axis share lines.  levels[idx] is the float distance of the reference's
+//    distances_lut_ (include/amcl/map/occupancy_map.h:99).
+//  * notfree_tiles: one bit per cell (1 = not CELL_FREE), 8x8 cells per 64-bit word;
+//    bits of cells beyond the map edge inside a partial tile are 1.
+//  * cells8: the tri-state grid narrowed to int8, row-major i + j*size_x.
+struct MapDev
+{
+  const uint16_t* lut_tiles;
+  const uint64_t* notfree_tiles;
+  const int8_t* cells8;
+  const float* levels;
+  int size_x, size_y;
+  int tiles_x, tiles_y;
+  int half_x, half_y;  // size/2, the centre offset of convertWorldToMap
+  int n_levels;        // K; index K is reserved for "off map"
+  double origin_x, origin_y;  // float origin promoted to double (occupancy_map.cpp:96-97)
+  double resolution;
+  double max_dist;
+};
+
+struct ParticlesDev
+{
+  double* x;
+  double* y;
+  double* th;
+  double* w;
+};
+
+struct GompertzDev
+{
+  double a, b, c, input_shift, input_scale, output_shift;
+};
+
+// Arguments of the likelihood-field family scoring kernel (LF / Gompertz / prob pass).
+struct FieldScoreArgs
+{
+  ParticlesDev p;
+  int n;
+  const double2* beams;  // per valid beam: r*cos(bearing)/res, r*sin(bearing)/res
+  int n_beams;
+  const double* table;   // per LUT level (+1 off-map entry): the per-beam term
+  int table_len;
+  MapDev map;
+  double sp_x, sp_y, sp_th;  // scanner pose in the robot frame
+  double off_map_factor, non_free_factor, non_free_radius;
+  int model;
+  GompertzDev g;
+  // prob model
+  const uint8_t* beam_mask;  // per valid-beam slot: 1 = integrate (nullable = all)
+  int* obs_count;            // per valid-beam slot agreement counts (nullable)
+  int skip_level;            // levels below this index are "z < beam_skip_distance"
+  int count_only;            // 1: only fill obs_count, leave weights alone
+};
+
+// drand48 jump-ahead tables: A[j] = a^(2^j), C[j] = c*(a^(2^j)-1)/(a-1)  (mod 2^48)
+struct LcgJump
+{
+  uint64_t A[48];
+  uint64_t C[48];
+};
+
+}  // namespace bpf

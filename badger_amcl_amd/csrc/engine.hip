@@ -1,0 +1,1791 @@
+// libbadger_pf_hip.so -- host engine and C-ABI (include/badger_pf.h) for the MI355X
+// sensor-update + resample path.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/badger_pf.h"
+#include "device_types.hpp"
+#include "kdhist.hpp"
+#include "kernels_pf.hpp"
+#include "kernels_score.hpp"
+
+using namespace bpf;
+
+namespace
+{
+
+constexpr int kRing = 4;            // in-flight scan uploads
+constexpr int kMaxBeams = 4096;     // beams staged in LDS per launch
+constexpr int kTableLdsMax = 2048;  // table entries that still go to LDS
+constexpr int kEventPool = 8192;
+
+template <typename T>
+struct DevBuf
+{
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap)
+      return hipSuccess;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t r = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+    if (r == hipSuccess)
+      cap = n;
+    return r;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+template <typename T>
+struct PinnedBuf
+{
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap)
+      return hipSuccess;
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(T), hipHostMallocDefault);
+    if (r == hipSuccess)
+      cap = n;
+    return r;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct SampleSet
+{
+  DevBuf<double> x, y, th, w;
+  ParticlesDev dev() { return ParticlesDev{ x.p, y.p, th.p, w.p }; }
+  hipError_t reserve(size_t n)
+  {
+    hipError_t r;
+    if ((r = x.reserve(n)) != hipSuccess) return r;
+    if ((r = y.reserve(n)) != hipSuccess) return r;
+    if ((r = th.reserve(n)) != hipSuccess) return r;
+    return w.reserve(n);
+  }
+  void release()
+  {
+    x.release(); y.release(); th.release(); w.release();
+  }
+};
+
+struct PlanarModel
+{
+  bool configured = false;
+  int model = BPF_MODEL_LIKELIHOOD_FIELD;
+  int max_beams = 0;
+  double z_hit = 0, z_short = 0, z_max = 0, z_rand = 0, sigma_hit = 0, lambda_short = 0;
+  GompertzDev g{ 0, 0, 0, 0, 0, 0 };
+  int do_beamskip = 0;
+  double beam_skip_distance = 0, beam_skip_threshold = 0, beam_skip_error_threshold = 0;
+  double off_map_factor = 1.0, non_free_factor = 1.0, non_free_radius = 0.0;  // planar_scanner.cpp:42-44
+  double pose[3] = { 0, 0, 0 };
+};
+
+struct ScanSlot
+{
+  PinnedBuf<unsigned char> host;
+  DevBuf<unsigned char> dev;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
+}  // namespace
+
+struct bpf_engine
+{
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // ---- 2-D map
+  bool have_map = false, have_lut = false;
+  MapDev map{};
+  int map_version = 0;
+  std::vector<int8_t> h_cells8;
+  std::vector<float> h_levels;
+  DevBuf<uint16_t> d_lut_tiles;
+  DevBuf<uint64_t> d_notfree;
+  DevBuf<int8_t> d_cells8;
+  DevBuf<float> d_levels;
+  DevBuf<float> d_lut_f32;
+  DevBuf<int> d_edt_tmp;
+
+  // ---- planar scanner
+  PlanarModel pm;
+  ScanSlot ring[kRing];
+  int ring_next = 0;
+  DevBuf<int> d_obs_count;
+  DevBuf<uint8_t> d_beam_mask;
+  DevBuf<unsigned long long> d_cells_walked;
+
+  // ---- particle filter
+  bool have_pf = false;
+  int min_samples = 0, max_samples = 0;
+  double alpha_slow = 0, alpha_fast = 0, conv_threshold = 0;
+  double pop_err = 0.01, pop_z = 3, dist_threshold = 0.5;  // particle_filter.cpp:58-60
+  int resample_model = BPF_RESAMPLE_MULTINOMIAL;
+  uint64_t rng = 0;  // glibc's unseeded drand48 state
+  LcgJump jump{};
+  SampleSet sets[2];
+  int cur = 0;
+  int sample_count = 0;
+  int leaf_count = 0, bin_count = 0;
+  int converged = 0;
+  float percent_converged = 0;
+  bool converged_pending = false;
+  double w_diff_last = 0;
+  int last_status = BPF_OK;
+  int resample_windows = 0;
+  int window_hint = 4096;
+  long long evals_last = 0;
+  bool cdf_serial = false;
+  bool count_cells = false;
+  KdHistogram hist;
+  DevBuf<double> d_cdf, d_partials, d_targets;
+  DevBuf<FilterScalars> d_scalars;
+  DevBuf<int> d_keys, d_src_index, d_flags;  // d_flags[0] miss, [1] converged count
+  DevBuf<double4> d_aos;
+  PinnedBuf<int> h_keys;
+  PinnedBuf<int> h_flags;
+  PinnedBuf<FilterScalars> h_scalars;
+  PinnedBuf<double4> h_aos;
+  SampleSet scratch;  // Seam A host-buffer path
+  SampleSet snap;
+  int snap_count = 0, snap_leaf = 0, snap_bins = 0;
+
+  // ---- profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  std::vector<int> ev_class;
+  size_t ev_used = 0;
+  bpf_profile prof{};
+
+  int fail(int code, const std::string& msg)
+  {
+    last_error = msg;
+    last_status = code;
+    return code;
+  }
+  int fail_hip(hipError_t r, const char* what)
+  {
+    return fail(BPF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(r));
+  }
+};
+
+#define HIPCHK(e, call)                          \
+  do                                             \
+  {                                              \
+    hipError_t _r = (call);                      \
+    if (_r != hipSuccess)                        \
+      return (e)->fail_hip(_r, #call);           \
+  } while (0)
+
+namespace
+{
+
+// ------------------------------------------------------------------ profiling helpers
+struct ProfScope
+{
+  bpf_engine* e;
+  int idx = -1;
+  ProfScope(bpf_engine* eng, int klass) : e(eng)
+  {
+    if (!e->profiling || e->ev_used >= e->ev_start.size())
+      return;
+    idx = (int)e->ev_used++;
+    e->ev_class[idx] = klass;
+    (void)hipEventRecord(e->ev_start[idx], e->stream);
+  }
+  ~ProfScope()
+  {
+    if (idx >= 0)
+      (void)hipEventRecord(e->ev_stop[idx], e->stream);
+  }
+};
+
+void lcg_tables(LcgJump& J)
+{
+  const uint64_t mask = (1ull << 48) - 1;
+  uint64_t a = 0x5DEECE66Dull, c = 0xBull;
+  for (int j = 0; j < 48; ++j)
+  {
+    J.A[j] = a;
+    J.C[j] = c;
+    c = (c * a + c) & mask;  // apply the step twice: x -> a*(a*x + c) + c
+    a = (a * a) & mask;
+  }
+}
+
+uint64_t lcg_skip_host(uint64_t x0, uint64_t n, const LcgJump& J)
+{
+  const uint64_t mask = (1ull << 48) - 1;
+  uint64_t a = 1, c = 0;
+  for (int j = 0; n != 0 && j < 48; ++j, n >>= 1)
+    if (n & 1)
+    {
+      a = (a * J.A[j]) & mask;
+      c = (c * J.A[j] + J.C[j]) & mask;
+    }
+  return (a * x0 + c) & mask;
+}
+
+int blocks_for(int n, int per_block)
+{
+  return (n + per_block - 1) / per_block;
+}
+
+// ------------------------------------------------------------------ map encoding
+int encode_lut(bpf_engine* e, const float* lut)
+{
+  const int sx = e->map.size_x, sy = e->map.size_y;
+  const size_t ncell = (size_t)sx * sy;
+  std::unordered_map<uint32_t, int> seen;
+  seen.reserve(4096);
+  std::vector<float> levels;
+  uint32_t last_bits = 0;
+  bool have_last = false;
+  for (size_t i = 0; i < ncell; ++i)
+  {
+    uint32_t bits;
+    std::memcpy(&bits, &lut[i], 4);
+    if (have_last && bits == last_bits)
+      continue;
+    last_bits = bits;
+    have_last = true;
+    if (seen.emplace(bits, 0).second)
+    {
+      levels.push_back(lut[i]);
+      if (levels.size() > 65535)
+        return e->fail(BPF_ERR_LUT_LEVELS, "distance LUT holds more than 65535 distinct values");
+    }
+  }
+  std::sort(levels.begin(), levels.end());
+  for (size_t k = 0; k < levels.size(); ++k)
+  {
+    uint32_t bits;
+    std::memcpy(&bits, &levels[k], 4);
+    seen[bits] = (int)k;
+  }
+  const int tx = e->map.tiles_x, ty = e->map.tiles_y;
+  std::vector<uint16_t> tiles((size_t)tx * ty * 64, 0);
+  for (int j = 0; j < sy; ++j)
+  {
+    uint32_t prev_bits = 0;
+    int prev_idx = -1;
+    for (int i = 0; i < sx; ++i)
+    {
+      uint32_t bits;
+      std::memcpy(&bits, &lut[i + (size_t)j * sx], 4);
+      if (prev_idx < 0 || bits != prev_bits)
+      {
+        prev_idx = seen[bits];
+        prev_bits = bits;
+      }
+      tiles[((size_t)(j >> 3) * tx + (i >> 3)) * 64 + ((j & 7) << 3) + (i & 7)] = (uint16_t)prev_idx;
+    }
+  }
+  HIPCHK(e, e->d_lut_tiles.reserve(tiles.size()));
+  HIPCHK(e, hipMemcpy(e->d_lut_tiles.p, tiles.data(), tiles.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_levels.reserve(levels.size() + 1));
+  HIPCHK(e, hipMemcpy(e->d_levels.p, levels.data(), levels.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_lut_f32.reserve(ncell));
+  HIPCHK(e, hipMemcpy(e->d_lut_f32.p, lut, ncell * sizeof(float), hipMemcpyHostToDevice));
+  e->h_levels = levels;
+  e->map.lut_tiles = e->d_lut_tiles.p;
+  e->map.levels = e->d_levels.p;
+  e->map.n_levels = (int)levels.size();
+  e->have_lut = true;
+  e->map_version++;
+  return BPF_OK;
+}
+
+int build_lut_device(bpf_engine* e, double max_dist)
+{
+  if (!e->have_map)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
+  if (max_dist == 0.0)
+    return BPF_OK;  // occupancy_map.cpp:141-145: leaves the LUT untouched
+  const int sx = e->map.size_x, sy = e->map.size_y;
+  const size_t ncell = (size_t)sx * sy;
+  const int radius = (int)std::floor(max_dist / e->map.resolution);
+  HIPCHK(e, e->d_edt_tmp.reserve(ncell));
+  HIPCHK(e, e->d_lut_f32.reserve(ncell));
+  dim3 grid(blocks_for(sx, 256), sy), block(256);
+  hipLaunchKernelGGL(k_edt_rows, grid, block, 0, e->stream, e->d_cells8.p, sx, sy, radius, e->d_edt_tmp.p);
+  hipLaunchKernelGGL(k_edt_cols, grid, block, 0, e->stream, e->d_edt_tmp.p, sx, sy, radius, e->map.resolution,
+                     max_dist, e->d_lut_f32.p);
+  HIPCHK(e, hipGetLastError());
+  std::vector<float> lut(ncell);
+  HIPCHK(e, hipMemcpyAsync(lut.data(), e->d_lut_f32.p, ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->map.max_dist = max_dist;
+  return encode_lut(e, lut.data());
+}
+
+// ------------------------------------------------------------------ scan staging
+int acquire_slot(bpf_engine* e, size_t bytes, ScanSlot** out)
+{
+  ScanSlot& s = e->ring[e->ring_next];
+  e->ring_next = (e->ring_next + 1) % kRing;
+  if (s.pending)
+  {
+    HIPCHK(e, hipEventSynchronize(s.done));
+    s.pending = false;
+  }
+  if (!s.done)
+    HIPCHK(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  HIPCHK(e, s.host.reserve(bytes));
+  HIPCHK(e, s.dev.reserve(bytes));
+  *out = &s;
+  return BPF_OK;
+}
+
+int release_slot(bpf_engine* e, ScanSlot* s)
+{
+  HIPCHK(e, hipEventRecord(s->done, e->stream));
+  s->pending = true;
+  return BPF_OK;
+}
+
+struct FieldScan
+{
+  int n_valid = 0;
+  int n_slots = 0;             // beam_ind range of the prob model
+  std::vector<int> slot_of;    // valid beam -> beam_ind
+  size_t beams_off = 0, table_off = 0, bytes = 0;
+  int table_len = 0;
+};
+
+// Host half of calcLikelihoodFieldModel{,Prob,Gompertz}: beam decimation and validity
+// (planar_scanner.cpp:265-282, :339-343,410-425, :578-597) and the per-level term table.
+int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, int rc, double range_max,
+                     ScanSlot** slot_out, FieldScan* fs)
+{
+  const PlanarModel& pm = e->pm;
+  int step;
+  if (pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB)
+    step = (int)std::ceil(rc / (double)pm.max_beams);
+  else
+    step = (rc - 1) / (pm.max_beams - 1);
+  if (step < 1)
+    step = 1;
+  const int K = e->map.n_levels;
+  fs->table_len = K + 1;
+  std::vector<double2> beams;
+  beams.reserve(rc / step + 1);
+  fs->slot_of.clear();
+  int slot = 0;
+  const double res = e->map.resolution;
+  for (int i = 0; i < rc; i += step, ++slot)
+  {
+    const double r = ranges[i];
+    if (r >= range_max)
+      continue;
+    if (r != r)
+      continue;
+    double2 b;
+    b.x = (r * std::cos(angles[i])) / res;
+    b.y = (r * std::sin(angles[i])) / res;
+    beams.push_back(b);
+    fs->slot_of.push_back(slot);
+  }
+  fs->n_slots = slot;
+  fs->n_valid = (int)beams.size();
+  if (fs->n_valid > kMaxBeams)
+    return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
+  fs->beams_off = 0;
+  fs->table_off = ((size_t)fs->n_valid * sizeof(double2) + 255) & ~(size_t)255;
+  fs->bytes = fs->table_off + (size_t)fs->table_len * sizeof(double);
+  ScanSlot* s;
+  int rcode = acquire_slot(e, fs->bytes, &s);
+  if (rcode != BPF_OK)
+    return rcode;
+  std::memcpy(s->host.p + fs->beams_off, beams.data(), beams.size() * sizeof(double2));
+  double* table = reinterpret_cast<double*>(s->host.p + fs->table_off);
+  const double denom = 2 * pm.sigma_hit * pm.sigma_hit;
+  const double rand_mult = 1.0 / range_max;
+  for (int k = 0; k <= K; ++k)
+  {
+    const bool off_map = (k == K);
+    const double z = off_map ? e->map.max_dist : (double)e->h_levels[k];
+    double pz = 0.0;
+    if (pm.model == BPF_MODEL_LIKELIHOOD_FIELD)
+    {
+      pz += pm.z_hit * std::exp(-(z * z) / denom);
+      pz += pm.z_rand * rand_mult;
+      table[k] = pz * pz * pz;
+    }
+    else if (pm.model == BPF_MODEL_LIKELIHOOD_FIELD_GOMPERTZ)
+    {
+      pz += pm.z_hit * std::exp(-(z * z) / denom);
+      pz += pm.z_rand;
+      table[k] = pz;
+    }
+    else
+    {
+      if (off_map)
+      {
+        const double max_dist_prob = std::exp(-(e->map.max_dist * e->map.max_dist) / denom);
+        pz += pm.z_hit * max_dist_prob;
+      }
+      else
+        pz += pm.z_hit * std::exp(-(z * z) / denom);
+      pz += pm.z_rand * rand_mult;
+      table[k] = std::log(pz);
+    }
+  }
+  HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs->bytes, hipMemcpyHostToDevice, e->stream));
+  *slot_out = s;
+  return BPF_OK;
+}
+
+int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldScan& fs, const uint8_t* mask,
+                 int* obs_count, int skip_level, int count_only)
+{
+  FieldScoreArgs A{};
+  A.p = p;
+  A.n = n;
+  A.beams = reinterpret_cast<const double2*>(s->dev.p + fs.beams_off);
+  A.n_beams = fs.n_valid;
+  A.table = reinterpret_cast<const double*>(s->dev.p + fs.table_off);
+  A.table_len = fs.table_len;
+  A.map = e->map;
+  A.sp_x = e->pm.pose[0];
+  A.sp_y = e->pm.pose[1];
+  A.sp_th = e->pm.pose[2];
+  A.off_map_factor = e->pm.off_map_factor;
+  A.non_free_factor = e->pm.non_free_factor;
+  A.non_free_radius = e->pm.non_free_radius;
+  A.model = e->pm.model;
+  A.g = e->pm.g;
+  A.beam_mask = mask;
+  A.obs_count = obs_count;
+  A.skip_level = skip_level;
+  A.count_only = count_only;
+  const bool table_lds = fs.table_len <= kTableLdsMax;
+  const size_t lds = (size_t)fs.n_valid * sizeof(double2) + (table_lds ? (size_t)fs.table_len * sizeof(double) : 0);
+  const int n_groups = (n + 15) / 16;
+  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1024));
+  per_cu = std::max(per_cu, 1);
+  const int grid = std::max(1, std::min(blocks_for(n_groups, 4), e->n_cu * per_cu));
+  ProfScope ps(e, BPF_K_SCORE);
+  if (table_lds)
+    hipLaunchKernelGGL(k_score_field<true>, dim3(grid), dim3(256), lds, e->stream, A);
+  else
+    hipLaunchKernelGGL(k_score_field<false>, dim3(grid), dim3(256), lds, e->stream, A);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+int sum_into_slot(bpf_engine* e, const double* v, int n, int slot, int update_averages, int n_samples)
+{
+  const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+  HIPCHK(e, e->d_partials.reserve((size_t)nb));
+  ProfScope ps(e, BPF_K_REDUCE);
+  hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, v, n, e->d_partials.p);
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_partials.p, nb, e->d_scalars.p,
+                     slot, update_averages, n_samples, e->alpha_slow, e->alpha_fast);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+int ensure_scalars(bpf_engine* e)
+{
+  if (e->d_scalars.p)
+    return BPF_OK;
+  HIPCHK(e, e->d_scalars.reserve(1));
+  HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
+  HIPCHK(e, e->h_scalars.reserve(1));
+  HIPCHK(e, e->d_flags.reserve(8));
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, 8 * sizeof(int), e->stream));
+  HIPCHK(e, e->h_flags.reserve(8));
+  return BPF_OK;
+}
+
+// Scores `n` particles of `p` with the configured planar model (+ recalcWeight).  Leaves the
+// weights un-normalised.  set_converged feeds the prob model's beam-skip switch.
+int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const double* ranges,
+                 const double* angles, int rc, double range_max, bool* forced_zero)
+{
+  *forced_zero = false;
+  if (!e->have_map)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
+  if (!e->have_lut)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "distance LUT missing (reference: isMapInitialized, node_2d.cpp:406-410)");
+  if (!e->pm.configured)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "planar model not set");
+  if (rc <= 0 || ranges == nullptr || angles == nullptr || n <= 0)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "empty scan or sample set");
+  const PlanarModel& pm = e->pm;
+  e->evals_last = 0;
+
+  if (pm.model == BPF_MODEL_BEAM)
+  {
+    const int step = (rc - 1) / (pm.max_beams - 1);  // planar_scanner.cpp:193, not clamped
+    if (step < 1)
+      return e->fail(BPF_ERR_BEAM_STEP, "beam model: range_count < max_beams makes the reference loop forever");
+    std::vector<BeamRec> beams;
+    for (int i = 0; i < rc; i += step)
+    {
+      BeamRec b;
+      b.cb = std::cos(angles[i]);
+      b.sb = std::sin(angles[i]);
+      b.obs = ranges[i];
+      b.short_t = pm.z_short * pm.lambda_short * std::exp(-pm.lambda_short * ranges[i]);
+      b.tail_t = 0.0;
+      if (ranges[i] == range_max)
+        b.tail_t = pm.z_max * 1.0;
+      if (ranges[i] < range_max)
+        b.tail_t = pm.z_rand * 1.0 / range_max;
+      beams.push_back(b);
+    }
+    if ((int)beams.size() > kMaxBeams)
+      return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
+    const size_t bytes = beams.size() * sizeof(BeamRec);
+    ScanSlot* s;
+    int rcode = acquire_slot(e, bytes, &s);
+    if (rcode != BPF_OK)
+      return rcode;
+    std::memcpy(s->host.p, beams.data(), bytes);
+    HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, bytes, hipMemcpyHostToDevice, e->stream));
+    BeamModelArgs A{};
+    A.p = p;
+    A.n = n;
+    A.beams = reinterpret_cast<const BeamRec*>(s->dev.p);
+    A.n_beams = (int)beams.size();
+    A.map = e->map;
+    A.sp_x = pm.pose[0];
+    A.sp_y = pm.pose[1];
+    A.sp_th = pm.pose[2];
+    A.off_map_factor = pm.off_map_factor;
+    A.non_free_factor = pm.non_free_factor;
+    A.non_free_radius = pm.non_free_radius;
+    A.range_max = range_max;
+    A.z_hit = pm.z_hit;
+    A.denom = 2 * pm.sigma_hit * pm.sigma_hit;
+    A.cells_walked = nullptr;
+    if (e->count_cells)
+    {
+      if (!e->d_cells_walked.p)
+      {
+        HIPCHK(e, e->d_cells_walked.reserve(1));
+        HIPCHK(e, hipMemsetAsync(e->d_cells_walked.p, 0, sizeof(unsigned long long), e->stream));
+      }
+      A.cells_walked = e->d_cells_walked.p;
+    }
+    const int n_groups = (n + 15) / 16;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(bytes, 1024)));
+    const int grid = std::max(1, std::min(blocks_for(n_groups, 4), e->n_cu * per_cu));
+    {
+      ProfScope ps(e, BPF_K_SCORE);
+      hipLaunchKernelGGL(k_score_beam, dim3(grid), dim3(256), bytes, e->stream, A);
+    }
+    HIPCHK(e, hipGetLastError());
+    e->evals_last = (long long)n * (long long)beams.size();
+    return release_slot(e, s);
+  }
+
+  ScanSlot* s = nullptr;
+  FieldScan fs;
+  int rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s, &fs);
+  if (rcode != BPF_OK)
+    return rcode;
+  e->evals_last = (long long)n * fs.n_valid;
+
+  const bool beamskip = pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && pm.do_beamskip && set_converged;
+  if (!beamskip)
+  {
+    rcode = launch_field(e, p, n, s, fs, nullptr, nullptr, 0, 0);
+    if (rcode != BPF_OK)
+      return rcode;
+    return release_slot(e, s);
+  }
+
+  // Beam skipping (planar_scanner.cpp:352-395,482-529): pass 1 counts, per beam, the particles
+  // whose end point lies within beam_skip_distance of an obstacle; the host forms the mask;
+  // pass 2 integrates the kept beams.  (The reference stores every pz in an N x max_beams
+  // scratch matrix between the passes; re-evaluating is cheaper than 8 B x N x beams of HBM.)
+  const int nv = std::max(fs.n_valid, 1);
+  HIPCHK(e, e->d_obs_count.reserve((size_t)nv));
+  HIPCHK(e, e->d_beam_mask.reserve((size_t)nv));
+  HIPCHK(e, hipMemsetAsync(e->d_obs_count.p, 0, (size_t)nv * sizeof(int), e->stream));
+  int skip_level = 0;  // levels are ascending: z < d  <=>  level index < first level >= d
+  while (skip_level < e->map.n_levels && (double)e->h_levels[skip_level] < pm.beam_skip_distance)
+    ++skip_level;
+  rcode = launch_field(e, p, n, s, fs, nullptr, e->d_obs_count.p, skip_level, 1);
+  if (rcode != BPF_OK)
+    return rcode;
+  std::vector<int> counts((size_t)nv, 0);
+  HIPCHK(e, hipMemcpyAsync(counts.data(), e->d_obs_count.p, (size_t)fs.n_valid * sizeof(int), hipMemcpyDeviceToHost,
+                           e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  std::vector<int> obs_count((size_t)pm.max_beams, 0);
+  for (int v = 0; v < fs.n_valid; ++v)
+    if (fs.slot_of[v] < pm.max_beams)
+      obs_count[fs.slot_of[v]] = counts[v];
+  std::vector<uint8_t> mask_slot((size_t)pm.max_beams, 0);
+  int skipped = 0;
+  for (int b = 0; b < pm.max_beams; ++b)
+  {
+    if ((obs_count[b] / (double)n) > pm.beam_skip_threshold)
+      mask_slot[b] = 1;
+    else
+      skipped++;
+  }
+  const bool error = skipped >= (pm.max_beams * pm.beam_skip_error_threshold);
+  // A kept slot that was never written holds 0.0 in the reference's scratch matrix, and
+  // log(0) = -inf zeroes every weight (planar_scanner.cpp:519-527).
+  std::vector<uint8_t> visited((size_t)pm.max_beams, 0);
+  for (int v = 0; v < fs.n_valid; ++v)
+    if (fs.slot_of[v] < pm.max_beams)
+      visited[fs.slot_of[v]] = 1;
+  bool poisoned = false;
+  for (int b = 0; b < pm.max_beams; ++b)
+    if ((error || mask_slot[b]) && !visited[b])
+      poisoned = true;
+  if (poisoned)
+  {
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, p.w, 0.0, n);
+    HIPCHK(e, hipGetLastError());
+    *forced_zero = true;
+    return release_slot(e, s);
+  }
+  std::vector<uint8_t> mask_valid((size_t)nv, 0);
+  for (int v = 0; v < fs.n_valid; ++v)
+    mask_valid[v] = error ? 1 : mask_slot[fs.slot_of[v]];
+  HIPCHK(e, hipMemcpyAsync(e->d_beam_mask.p, mask_valid.data(), (size_t)fs.n_valid, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // mask_valid is pageable and about to go out of scope
+  rcode = launch_field(e, p, n, s, fs, e->d_beam_mask.p, nullptr, 0, 0);
+  if (rcode != BPF_OK)
+    return rcode;
+  return release_slot(e, s);
+}
+
+int fetch_scalars(bpf_engine* e)
+{
+  HIPCHK(e, hipMemcpyAsync(e->h_scalars.p, e->d_scalars.p, sizeof(FilterScalars), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->h_flags.p, e->d_flags.p, 8 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (e->converged_pending)
+  {
+    // particle_filter.cpp:206-219, float arithmetic for the percentage
+    const double pct = (float)e->h_flags.p[1] / (float)e->sample_count * 100;
+    e->percent_converged = (float)pct;
+    e->converged = pct >= e->conv_threshold;
+    e->converged_pending = false;
+  }
+  return BPF_OK;
+}
+
+int build_cdf(bpf_engine* e, const double* w, int n)
+{
+  HIPCHK(e, e->d_cdf.reserve((size_t)n + 1));
+  ProfScope ps(e, BPF_K_CDF);
+  if (e->cdf_serial)
+  {
+    hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, e->stream, w, n, e->d_cdf.p);
+  }
+  else
+  {
+    const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+    HIPCHK(e, e->d_partials.reserve((size_t)nb));
+    hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, e->d_partials.p);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_partials.p, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, e->d_partials.p, e->d_cdf.p);
+  }
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+// updateConverged (particle_filter.cpp:170-220) on the current set, result fetched lazily
+int launch_converged(bpf_engine* e)
+{
+  SampleSet& s = e->sets[e->cur];
+  const int n = e->sample_count;
+  int rcode = sum_into_slot(e, s.x.p, n, 3, 0, n);
+  if (rcode != BPF_OK)
+    return rcode;
+  rcode = sum_into_slot(e, s.y.p, n, 4, 0, n);
+  if (rcode != BPF_OK)
+    return rcode;
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p + 1, 0, sizeof(int), e->stream));
+  const int grid = std::max(1, std::min(blocks_for(n, 256), 1024));
+  hipLaunchKernelGGL(k_count_converged, dim3(grid), dim3(256), 0, e->stream, s.x.p, s.y.p, n, e->d_scalars.p,
+                     e->dist_threshold, e->d_flags.p + 1);
+  HIPCHK(e, hipGetLastError());
+  e->converged_pending = true;
+  return BPF_OK;
+}
+
+int resample_multinomial(bpf_engine* e)
+{
+  SampleSet& a = e->sets[e->cur];
+  SampleSet& b = e->sets[e->cur ^ 1];
+  const int n = e->sample_count;
+  const int maxs = e->max_samples;
+  HIPCHK(e, e->d_keys.reserve((size_t)maxs * 3));
+  HIPCHK(e, e->d_src_index.reserve((size_t)maxs));
+  HIPCHK(e, e->h_keys.reserve((size_t)maxs * 3));
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
+  e->hist.clear();
+  int m0 = 0, stop = -1;
+  int window = std::max(1024, std::min(e->window_hint, maxs));
+  e->resample_windows = 0;
+  int cached_leaf = -1, cached_limit = 0;
+  while (m0 < maxs && stop < 0)
+  {
+    const int m1 = std::min(maxs, m0 + window);
+    DrawArgs A{};
+    A.src = a.dev();
+    A.n_src = n;
+    A.cdf = e->d_cdf.p;
+    A.dst = b.dev();
+    A.m0 = m0;
+    A.m1 = m1;
+    A.rng_state = e->rng;
+    A.jump = e->jump;
+    A.keys = e->d_keys.p;
+    A.src_index = e->d_src_index.p;
+    A.miss_flag = e->d_flags.p;
+    A.sharded = 0;
+    {
+      ProfScope ps(e, BPF_K_DRAW);
+      hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(m1 - m0, 256)), dim3(256), 0, e->stream, A);
+    }
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)(m1 - m0) * 3 * sizeof(int), hipMemcpyDeviceToHost,
+                             e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->resample_windows++;
+    const int* keys = e->h_keys.p;
+    for (int m = m0; m < m1; ++m)
+    {
+      const int* k = &keys[3 * (m - m0)];
+      e->hist.insert(k[0], k[1], k[2]);
+      const int lc = e->hist.leaf_count();
+      if (lc != cached_leaf)
+      {
+        cached_leaf = lc;
+        cached_limit = resample_limit(lc, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+      }
+      if (m + 1 > cached_limit)  // particle_filter.cpp:416
+      {
+        stop = m + 1;
+        break;
+      }
+    }
+    m0 = m1;
+    window *= 4;
+  }
+  const int M = (stop > 0) ? stop : maxs;
+  // the window that found the stop also inserted nothing past it: hist is exactly set b's tree
+  e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)M, e->jump);
+  e->window_hint = std::max(1024, ((M + M / 4) + 1023) / 1024 * 1024);
+  e->sample_count = M;
+  return BPF_OK;
+}
+
+int resample_systematic(bpf_engine* e)
+{
+  SampleSet& a = e->sets[e->cur];
+  SampleSet& b = e->sets[e->cur ^ 1];
+  const int n = e->sample_count;
+  const int count = resample_limit(e->leaf_count, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+  e->rng = lcg_skip_host(e->rng, 1, e->jump);
+  const double start = std::ldexp((double)e->rng, -48);
+  const double delta = 1.0 / count;
+  HIPCHK(e, e->d_targets.reserve((size_t)e->max_samples));
+  HIPCHK(e, e->d_keys.reserve((size_t)e->max_samples * 3));
+  HIPCHK(e, e->d_src_index.reserve((size_t)e->max_samples));
+  HIPCHK(e, e->h_keys.reserve((size_t)e->max_samples * 3));
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
+  SystematicArgs A{};
+  A.src = a.dev();
+  A.n_src = n;
+  A.cdf = e->d_cdf.p;
+  A.targets = e->d_targets.p;
+  A.dst = b.dev();
+  A.count = count;
+  A.keys = e->d_keys.p;
+  A.src_index = e->d_src_index.p;
+  A.miss_flag = e->d_flags.p;
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_systematic_targets, dim3(1), dim3(64), 0, e->stream, start, delta, count, e->d_targets.p);
+    hipLaunchKernelGGL(k_systematic_select, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream, A);
+  }
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)count * 3 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->hist.clear();
+  for (int m = 0; m < count; ++m)
+    e->hist.insert(e->h_keys.p[3 * m], e->h_keys.p[3 * m + 1], e->h_keys.p[3 * m + 2]);
+  e->resample_windows = 1;
+  e->sample_count = count;
+  return BPF_OK;
+}
+
+int upload_samples(bpf_engine* e, const double* aos, int n, SampleSet& dst)
+{
+  HIPCHK(e, e->h_aos.reserve((size_t)n));
+  HIPCHK(e, e->d_aos.reserve((size_t)n));
+  HIPCHK(e, dst.reserve((size_t)n));
+  std::memcpy(e->h_aos.p, aos, (size_t)n * sizeof(double4));
+  HIPCHK(e, hipMemcpyAsync(e->d_aos.p, e->h_aos.p, (size_t)n * sizeof(double4), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->d_aos.p, dst.dev(), n);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C-ABI
+extern "C" {
+
+int bpf_create(int device_ordinal, bpf_engine** out)
+{
+  if (!out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return BPF_ERR_HIP;  // no GPU: the product path fails loudly, there is no CPU fallback
+  if (device_ordinal < 0 || device_ordinal >= count)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(device_ordinal) != hipSuccess)
+    return BPF_ERR_HIP;
+  bpf_engine* e = new bpf_engine();
+  e->device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess)
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    delete e;
+    return BPF_ERR_HIP;
+  }
+  e->stream = e->own_stream;
+  lcg_tables(e->jump);
+  *out = e;
+  return BPF_OK;
+}
+
+void bpf_destroy(bpf_engine* e)
+{
+  if (!e)
+    return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto& s : e->ring)
+  {
+    s.host.release();
+    s.dev.release();
+    if (s.done)
+      (void)hipEventDestroy(s.done);
+  }
+  for (auto ev : e->ev_start)
+    (void)hipEventDestroy(ev);
+  for (auto ev : e->ev_stop)
+    (void)hipEventDestroy(ev);
+  e->d_lut_tiles.release(); e->d_notfree.release(); e->d_cells8.release(); e->d_levels.release();
+  e->d_lut_f32.release(); e->d_edt_tmp.release(); e->d_obs_count.release(); e->d_beam_mask.release();
+  e->d_cells_walked.release();
+  e->sets[0].release(); e->sets[1].release(); e->scratch.release(); e->snap.release();
+  e->d_cdf.release(); e->d_partials.release(); e->d_targets.release(); e->d_scalars.release();
+  e->d_keys.release(); e->d_src_index.release(); e->d_flags.release(); e->d_aos.release();
+  e->h_keys.release(); e->h_flags.release(); e->h_scalars.release(); e->h_aos.release();
+  if (e->own_stream)
+    (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+const char* bpf_error_string(int code)
+{
+  switch (code)
+  {
+    case BPF_OK: return "ok";
+    case BPF_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case BPF_ERR_NOT_CONFIGURED: return "map, model or filter not configured";
+    case BPF_ERR_HIP: return "HIP runtime error (or no GPU present)";
+    case BPF_ERR_UNSUPPORTED: return "unsupported on the device path";
+    case BPF_ERR_CDF_MISS: return "CDF search found no interval (reference asserts)";
+    case BPF_ERR_LUT_LEVELS: return "distance LUT has too many distinct values";
+    case BPF_ERR_BEAM_STEP: return "beam model step is zero (reference never returns)";
+    case BPF_ERR_CAPACITY: return "capacity exceeded";
+    default: return "unknown";
+  }
+}
+
+const char* bpf_last_error_message(const bpf_engine* e)
+{
+  return e ? e->last_error.c_str() : "null engine";
+}
+
+int bpf_set_stream(bpf_engine* e, void* hip_stream)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
+  return BPF_OK;
+}
+
+int bpf_synchronize(bpf_engine* e)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return BPF_OK;
+}
+
+// ---------------------------------------------------------------------- 2-D map
+int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, int size_x, int size_y, float origin_x,
+                  float origin_y, double resolution, double max_dist)
+{
+  if (!e || !cells || size_x <= 0 || size_y <= 0 || !(resolution > 0))
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad map arguments") : BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const size_t ncell = (size_t)size_x * size_y;
+  MapDev& M = e->map;
+  M.size_x = size_x;
+  M.size_y = size_y;
+  M.tiles_x = (size_x + 7) / 8;
+  M.tiles_y = (size_y + 7) / 8;
+  M.half_x = size_x / 2;
+  M.half_y = size_y / 2;
+  M.origin_x = (double)origin_x;
+  M.origin_y = (double)origin_y;
+  M.resolution = resolution;
+  M.max_dist = max_dist;
+  M.n_levels = 0;
+  e->h_cells8.resize(ncell);
+  for (size_t i = 0; i < ncell; ++i)
+    e->h_cells8[i] = (int8_t)cells[i];
+  std::vector<uint64_t> nf((size_t)M.tiles_x * M.tiles_y, ~0ull);
+  for (int j = 0; j < size_y; ++j)
+    for (int i = 0; i < size_x; ++i)
+      if (cells[i + (size_t)j * size_x] == -1)
+        nf[(size_t)(j >> 3) * M.tiles_x + (i >> 3)] &= ~(1ull << (((j & 7) << 3) | (i & 7)));
+  HIPCHK(e, e->d_cells8.reserve(ncell));
+  HIPCHK(e, hipMemcpy(e->d_cells8.p, e->h_cells8.data(), ncell, hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_notfree.reserve(nf.size()));
+  HIPCHK(e, hipMemcpy(e->d_notfree.p, nf.data(), nf.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  M.cells8 = e->d_cells8.p;
+  M.notfree_tiles = e->d_notfree.p;
+  M.lut_tiles = nullptr;
+  M.levels = nullptr;
+  e->have_map = true;
+  e->have_lut = false;
+  e->map_version++;
+  if (dist_lut)
+    return encode_lut(e, dist_lut);
+  return BPF_OK;
+}
+
+int bpf_map2d_build_distances_lut(bpf_engine* e, double max_dist)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  return build_lut_device(e, max_dist);
+}
+
+int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity)
+{
+  if (!e || !out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_lut)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no distance LUT");
+  const size_t ncell = (size_t)e->map.size_x * e->map.size_y;
+  if (capacity < ncell)
+    return e->fail(BPF_ERR_CAPACITY, "output too small");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(out, e->d_lut_f32.p, ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return BPF_OK;
+}
+
+// ---------------------------------------------------------------------- planar scanner
+int bpf_planar_init(bpf_engine* e, int max_beams)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->pm.max_beams = max_beams;
+  return BPF_OK;
+}
+
+static int need_lut_for(bpf_engine* e, double max_dist)
+{
+  // setModelLikelihoodField* call map_->updateDistancesLUT(max_dist) (planar_scanner.cpp:74,91,112).
+  // A host-provided LUT built for the same max_dist is kept; otherwise build on the device.
+  if (!e->have_map)
+    return BPF_OK;  // model may be set before the map; the LUT is then required at scoring time
+  if (e->have_lut && e->map.max_dist == max_dist)
+    return BPF_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  return build_lut_device(e, max_dist);
+}
+
+int bpf_planar_set_model_beam(bpf_engine* e, double z_hit, double z_short, double z_max, double z_rand,
+                              double sigma_hit, double lambda_short)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  PlanarModel& p = e->pm;
+  p.model = BPF_MODEL_BEAM;
+  p.z_hit = z_hit; p.z_short = z_short; p.z_max = z_max; p.z_rand = z_rand;
+  p.sigma_hit = sigma_hit; p.lambda_short = lambda_short;
+  p.configured = true;
+  return BPF_OK;
+}
+
+int bpf_planar_set_model_likelihood_field(bpf_engine* e, double z_hit, double z_rand, double sigma_hit,
+                                          double max_distance_to_object)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  PlanarModel& p = e->pm;
+  p.model = BPF_MODEL_LIKELIHOOD_FIELD;
+  p.z_hit = z_hit; p.z_rand = z_rand; p.sigma_hit = sigma_hit;
+  p.configured = true;
+  return need_lut_for(e, max_distance_to_object);
+}
+
+int bpf_planar_set_model_likelihood_field_prob(bpf_engine* e, double z_hit, double z_rand, double sigma_hit,
+                                               double max_distance_to_object, int do_beamskip,
+                                               double beam_skip_distance, double beam_skip_threshold,
+                                               double beam_skip_error_threshold)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  PlanarModel& p = e->pm;
+  p.model = BPF_MODEL_LIKELIHOOD_FIELD_PROB;
+  p.z_hit = z_hit; p.z_rand = z_rand; p.sigma_hit = sigma_hit;
+  p.do_beamskip = do_beamskip;
+  p.beam_skip_distance = beam_skip_distance;
+  p.beam_skip_threshold = beam_skip_threshold;
+  p.beam_skip_error_threshold = beam_skip_error_threshold;
+  p.configured = true;
+  return need_lut_for(e, max_distance_to_object);
+}
+
+int bpf_planar_set_model_likelihood_field_gompertz(bpf_engine* e, double z_hit, double z_rand, double sigma_hit,
+                                                   double max_distance_to_object, double gompertz_a,
+                                                   double gompertz_b, double gompertz_c, double input_shift,
+                                                   double input_scale, double output_shift)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  PlanarModel& p = e->pm;
+  p.model = BPF_MODEL_LIKELIHOOD_FIELD_GOMPERTZ;
+  p.z_hit = z_hit; p.z_rand = z_rand; p.sigma_hit = sigma_hit;
+  p.g = GompertzDev{ gompertz_a, gompertz_b, gompertz_c, input_shift, input_scale, output_shift };
+  p.configured = true;
+  return need_lut_for(e, max_distance_to_object);
+}
+
+int bpf_planar_set_map_factors(bpf_engine* e, double off_map_factor, double non_free_space_factor,
+                               double non_free_space_radius)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->pm.off_map_factor = off_map_factor;
+  e->pm.non_free_factor = non_free_space_factor;
+  e->pm.non_free_radius = non_free_space_radius;
+  return BPF_OK;
+}
+
+int bpf_planar_set_scanner_pose(bpf_engine* e, const double pose[3])
+{
+  if (!e || !pose)
+    return BPF_ERR_INVALID_ARGUMENT;
+  std::memcpy(e->pm.pose, pose, 3 * sizeof(double));
+  return BPF_OK;
+}
+
+double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int sample_count, int set_converged,
+                                            const double* ranges, const double* angles, int range_count,
+                                            double range_max, int* status)
+{
+  int dummy;
+  if (!status)
+    status = &dummy;
+  *status = BPF_OK;
+  if (!e || !samples)
+  {
+    *status = BPF_ERR_INVALID_ARGUMENT;
+    return 0.0;
+  }
+  if (e->pm.max_beams < 2)
+    return 0.0;  // planar_scanner.cpp:144-145
+  auto bail = [&](int code) { *status = code; return 0.0; };
+  if (hipSetDevice(e->device) != hipSuccess)
+    return bail(e->fail(BPF_ERR_HIP, "hipSetDevice"));
+  int rc = ensure_scalars(e);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = upload_samples(e, samples, sample_count, e->scratch);
+  if (rc != BPF_OK)
+    return bail(rc);
+  bool forced_zero = false;
+  rc = score_planar(e, e->scratch.dev(), sample_count, set_converged, ranges, angles, range_count, range_max,
+                    &forced_zero);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = sum_into_slot(e, e->scratch.w.p, sample_count, 0, 0, sample_count);
+  if (rc != BPF_OK)
+    return bail(rc);
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(sample_count, 256)), dim3(256), 0, e->stream, e->scratch.dev(),
+                     e->d_aos.p, sample_count);
+  if (hipMemcpyAsync(e->h_aos.p, e->d_aos.p, (size_t)sample_count * sizeof(double4), hipMemcpyDeviceToHost,
+                     e->stream) != hipSuccess ||
+      hipMemcpyAsync(e->h_scalars.p, e->d_scalars.p, sizeof(FilterScalars), hipMemcpyDeviceToHost, e->stream) !=
+          hipSuccess ||
+      hipStreamSynchronize(e->stream) != hipSuccess)
+    return bail(e->fail(BPF_ERR_HIP, "copy back"));
+  for (int i = 0; i < sample_count; ++i)
+    samples[4 * i + 3] = e->h_aos.p[i].w;
+  return e->h_scalars.p->v[0];
+}
+
+// ---------------------------------------------------------------------- particle filter
+int bpf_pf_create(bpf_engine* e, int min_samples, int max_samples, double alpha_slow, double alpha_fast,
+                  double global_localization_convergence_threshold)
+{
+  if (!e || max_samples <= 0 || min_samples < 0)
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad filter sizes") : BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = ensure_scalars(e);
+  if (rc != BPF_OK)
+    return rc;
+  e->min_samples = min_samples;
+  e->max_samples = max_samples;
+  e->alpha_slow = alpha_slow;
+  e->alpha_fast = alpha_fast;
+  e->conv_threshold = global_localization_convergence_threshold;
+  e->pop_err = 0.01;
+  e->pop_z = 3;
+  e->dist_threshold = 0.5;
+  e->resample_model = BPF_RESAMPLE_MULTINOMIAL;
+  for (int k = 0; k < 2; ++k)
+    HIPCHK(e, e->sets[k].reserve((size_t)max_samples));
+  // ctor state (particle_filter.cpp:62-89): max_samples particles at the origin, weight 1/max
+  e->cur = 0;
+  e->sample_count = max_samples;
+  HIPCHK(e, hipMemsetAsync(e->sets[0].x.p, 0, (size_t)max_samples * sizeof(double), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->sets[0].y.p, 0, (size_t)max_samples * sizeof(double), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->sets[0].th.p, 0, (size_t)max_samples * sizeof(double), e->stream));
+  hipLaunchKernelGGL(k_fill, dim3(blocks_for(max_samples, 256)), dim3(256), 0, e->stream, e->sets[0].w.p,
+                     1.0 / max_samples, max_samples);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
+  e->leaf_count = 0;
+  e->bin_count = 0;
+  e->converged = 0;
+  e->converged_pending = false;
+  e->window_hint = 4096;
+  e->have_pf = true;
+  return BPF_OK;
+}
+
+int bpf_pf_set_resample_model(bpf_engine* e, int resample_model)
+{
+  if (!e || (resample_model != BPF_RESAMPLE_MULTINOMIAL && resample_model != BPF_RESAMPLE_SYSTEMATIC))
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->resample_model = resample_model;
+  return BPF_OK;
+}
+
+int bpf_pf_set_population_size_parameters(bpf_engine* e, double pop_err, double pop_z)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->pop_err = pop_err;
+  e->pop_z = pop_z;
+  return BPF_OK;
+}
+
+int bpf_pf_set_decay_rates(bpf_engine* e, double alpha_slow, double alpha_fast)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->alpha_slow = alpha_slow;
+  e->alpha_fast = alpha_fast;
+  return BPF_OK;
+}
+
+int bpf_pf_srand48(bpf_engine* e, long seed)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->rng = ((((uint64_t)seed) & 0xFFFFFFFFull) << 16) | 0x330Eull;
+  return BPF_OK;
+}
+
+int bpf_pf_set_rng_state(bpf_engine* e, uint64_t state48)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->rng = state48 & ((1ull << 48) - 1);
+  return BPF_OK;
+}
+
+int bpf_pf_get_rng_state(const bpf_engine* e, uint64_t* state48)
+{
+  if (!e || !state48)
+    return BPF_ERR_INVALID_ARGUMENT;
+  *state48 = e->rng;
+  return BPF_OK;
+}
+
+int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, int leaf_count)
+{
+  if (!e || !samples)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  if (sample_count <= 0 || sample_count > e->max_samples)
+    return e->fail(BPF_ERR_CAPACITY, "sample_count outside (0, max_samples]");
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = upload_samples(e, samples, sample_count, e->sets[e->cur]);
+  if (rc != BPF_OK)
+    return rc;
+  e->sample_count = sample_count;
+  // initWith*: w_slow_ = w_fast_ = 0, converged = false (particle_filter.cpp:127,157,164-168)
+  HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
+  e->converged = 0;
+  e->converged_pending = false;
+  if (leaf_count >= 0)
+  {
+    e->leaf_count = leaf_count;
+    e->bin_count = -1;
+  }
+  else
+  {
+    e->hist.clear();
+    for (int i = 0; i < sample_count; ++i)
+    {
+      int key[3];
+      host_pose_key(samples[4 * i], samples[4 * i + 1], samples[4 * i + 2], key);
+      e->hist.insert(key[0], key[1], key[2]);
+    }
+    e->leaf_count = e->hist.leaf_count();
+    e->bin_count = e->hist.bin_count();
+  }
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // h_aos staging is reused by the next call
+  return BPF_OK;
+}
+
+int bpf_pf_get_samples(bpf_engine* e, double* samples_out, int capacity, int* sample_count_out)
+{
+  if (!e || !samples_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  const int n = e->sample_count;
+  if (capacity < n)
+    return e->fail(BPF_ERR_CAPACITY, "output too small");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, e->d_aos.reserve((size_t)n));
+  HIPCHK(e, e->h_aos.reserve((size_t)n));
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->sets[e->cur].dev(),
+                     e->d_aos.p, n);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(e->h_aos.p, e->d_aos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  std::memcpy(samples_out, e->h_aos.p, (size_t)n * sizeof(double4));
+  if (sample_count_out)
+    *sample_count_out = n;
+  return BPF_OK;
+}
+
+int bpf_pf_snapshot(bpf_engine* e)
+{
+  if (!e || !e->have_pf)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t n = (size_t)e->sample_count;
+  HIPCHK(e, e->snap.reserve(n));
+  SampleSet& s = e->sets[e->cur];
+  HIPCHK(e, hipMemcpyAsync(e->snap.x.p, s.x.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->snap.y.p, s.y.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->snap.th.p, s.th.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->snap.w.p, s.w.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  e->snap_count = e->sample_count;
+  e->snap_leaf = e->leaf_count;
+  e->snap_bins = e->bin_count;
+  return BPF_OK;
+}
+
+int bpf_pf_restore(bpf_engine* e)
+{
+  if (!e || !e->have_pf || e->snap_count <= 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t n = (size_t)e->snap_count;
+  SampleSet& s = e->sets[e->cur];
+  HIPCHK(e, hipMemcpyAsync(s.x.p, e->snap.x.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(s.y.p, e->snap.y.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(s.th.p, e->snap.th.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(s.w.p, e->snap.w.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  e->sample_count = e->snap_count;
+  e->leaf_count = e->snap_leaf;
+  e->bin_count = e->snap_bins;
+  return BPF_OK;
+}
+
+int bpf_pf_fill_weights(bpf_engine* e, double weight)
+{
+  if (!e || !e->have_pf)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_fill, dim3(blocks_for(e->sample_count, 256)), dim3(256), 0, e->stream,
+                     e->sets[e->cur].w.p, weight, e->sample_count);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+int bpf_pf_update_sensor_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                                double range_max)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  if (e->pm.max_beams < 2)
+    return BPF_OK;  // PlanarScanner::updateSensor returns false and touches nothing (:128-129)
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && e->pm.do_beamskip && e->converged_pending)
+  {
+    int rc = fetch_scalars(e);
+    if (rc != BPF_OK)
+      return rc;
+  }
+  SampleSet& s = e->sets[e->cur];
+  const int n = e->sample_count;
+  bool forced_zero = false;
+  int rc = score_planar(e, s.dev(), n, e->converged, ranges, angles, range_count, range_max, &forced_zero);
+  if (rc != BPF_OK)
+    return rc;
+  rc = sum_into_slot(e, s.w.p, n, 0, 1, n);
+  if (rc != BPF_OK)
+    return rc;
+  {
+    ProfScope ps(e, BPF_K_NORMALIZE);
+    hipLaunchKernelGGL(k_normalize, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.w.p, n, e->d_scalars.p, 0,
+                       0.0, n);
+  }
+  HIPCHK(e, hipGetLastError());
+  e->last_status = BPF_OK;
+  return BPF_OK;
+}
+
+int bpf_pf_update_resample(bpf_engine* e)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  // w_diff = max(0, 1 - w_fast/w_slow) (particle_filter.cpp:438-440).  With both decay rates
+  // zero the two averages are always equal, so w_diff is 0 (or NaN before any update, which
+  // the multinomial sampler treats as 0 too) and no read-back is needed.
+  double w_diff = 0.0;
+  if (e->alpha_slow != 0.0 || e->alpha_fast != 0.0)
+  {
+    int rc = fetch_scalars(e);
+    if (rc != BPF_OK)
+      return rc;
+    const double ws = e->h_scalars.p->v[1], wf = e->h_scalars.p->v[2];
+    w_diff = 1.0 - wf / ws;
+    if (!(w_diff >= 0.0))
+      w_diff = 0.0;
+    if (w_diff > 0.0)
+      return e->fail(BPF_ERR_UNSUPPORTED,
+                     "w_diff > 0: random pose injection needs the node's random_pose_fn_ callback "
+                     "(particle_filter.cpp:385-388); not available on the device path");
+  }
+  e->w_diff_last = w_diff;
+  SampleSet& a = e->sets[e->cur];
+  int rc = build_cdf(e, a.w.p, e->sample_count);
+  if (rc != BPF_OK)
+    return rc;
+  rc = (e->resample_model == BPF_RESAMPLE_SYSTEMATIC) ? resample_systematic(e) : resample_multinomial(e);
+  if (rc != BPF_OK)
+    return rc;
+  const int M = e->sample_count;
+  SampleSet& b = e->sets[e->cur ^ 1];
+  {
+    ProfScope ps(e, BPF_K_FINALIZE);
+    // weight 1.0 each, total = M, then weight /= total (particle_filter.cpp:409,458-462)
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(M, 256)), dim3(256), 0, e->stream, b.w.p, 1.0 / (double)M, M);
+  }
+  HIPCHK(e, hipGetLastError());
+  e->cur ^= 1;
+  e->leaf_count = e->hist.leaf_count();
+  e->bin_count = e->hist.bin_count();
+  rc = launch_converged(e);
+  if (rc != BPF_OK)
+    return rc;
+  // miss flag was copied? read it with the next fetch; report asynchronously via last_status
+  e->last_status = BPF_OK;
+  return BPF_OK;
+}
+
+int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out)
+{
+  if (!e || !out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = fetch_scalars(e);
+  if (rc != BPF_OK)
+    return rc;
+  if (e->h_flags.p[0] != 0 && e->last_status == BPF_OK)
+    e->last_status = BPF_ERR_CDF_MISS;
+  std::memset(out, 0, sizeof(*out));
+  out->sample_count = e->sample_count;
+  out->leaf_count = e->leaf_count;
+  out->bin_count = e->bin_count;
+  out->converged = e->converged;
+  out->percent_converged = e->percent_converged;
+  out->total = e->h_scalars.p->v[0];
+  out->w_slow = e->h_scalars.p->v[1];
+  out->w_fast = e->h_scalars.p->v[2];
+  out->w_diff = e->w_diff_last;
+  out->last_status = e->last_status;
+  out->resample_windows = e->resample_windows;
+  out->evals = e->evals_last;
+  return BPF_OK;
+}
+
+// ---------------------------------------------------------------------- 3-D (next milestone)
+int bpf_map3d_set(bpf_engine* e, const uint32_t*, size_t, const uint8_t*, size_t, const int*, const int*, double,
+                  double)
+{
+  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : BPF_ERR_INVALID_ARGUMENT;
+}
+int bpf_cloud_init(bpf_engine* e, int) { return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1; }
+int bpf_cloud_set_model(bpf_engine* e, double, double, double)
+{
+  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+}
+int bpf_cloud_set_model_gompertz(bpf_engine* e, double, double, double, double, double, double, double, double, double)
+{
+  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+}
+int bpf_cloud_set_map_factors(bpf_engine* e, double, double, double)
+{
+  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+}
+int bpf_cloud_set_scanner_to_footprint_tf(bpf_engine* e, const double*, const double*)
+{
+  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+}
+double bpf_cloud_apply_model_to_sample_set(bpf_engine* e, double*, int, const float*, int, int* status)
+{
+  if (status)
+    *status = BPF_ERR_UNSUPPORTED;
+  if (e)
+    e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet");
+  return 0.0;
+}
+int bpf_pf_update_sensor_cloud(bpf_engine* e, const float*, int)
+{
+  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+}
+
+// ---------------------------------------------------------------------- sharded stages
+int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                           double range_max)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  if (e->pm.max_beams < 2)
+    return BPF_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& s = e->sets[e->cur];
+  bool forced_zero = false;
+  int rc = score_planar(e, s.dev(), e->sample_count, e->converged, ranges, angles, range_count, range_max,
+                        &forced_zero);
+  if (rc != BPF_OK)
+    return rc;
+  return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
+}
+
+int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr)
+{
+  if (!e || !dev_ptr)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = ensure_scalars(e);
+  if (rc != BPF_OK)
+    return rc;
+  *dev_ptr = e->d_scalars.p;
+  return BPF_OK;
+}
+
+int bpf_shard_normalize(bpf_engine* e, double global_total, int global_sample_count)
+{
+  if (!e || !e->have_pf)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& s = e->sets[e->cur];
+  const int n = e->sample_count;
+  hipLaunchKernelGGL(k_normalize, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.w.p, n, e->d_scalars.p, 1,
+                     global_total, global_sample_count);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+int bpf_shard_build_cdf(bpf_engine* e, double* local_sum_out)
+{
+  if (!e || !e->have_pf || !local_sum_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = build_cdf(e, e->sets[e->cur].w.p, e->sample_count);
+  if (rc != BPF_OK)
+    return rc;
+  HIPCHK(e, hipMemcpyAsync(local_sum_out, e->d_cdf.p + e->sample_count, sizeof(double), hipMemcpyDeviceToHost,
+                           e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return BPF_OK;
+}
+
+int bpf_shard_draw_select(bpf_engine* e, uint64_t rng_state48, int m0, int m1, double cdf_offset, int is_last_shard,
+                          int* draw_index_out, double* poses_out, int* keys_out, int capacity, int* count_out,
+                          int* miss_out)
+{
+  if (!e || !e->have_pf || !draw_index_out || !poses_out || !keys_out || !count_out || m1 < m0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  const int w = m1 - m0;
+  SampleSet& a = e->sets[e->cur];
+  HIPCHK(e, e->d_keys.reserve((size_t)std::max(w, 1) * 3));
+  HIPCHK(e, e->d_src_index.reserve((size_t)std::max(w, 1)));
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
+  DrawArgs A{};
+  A.src = a.dev();
+  A.n_src = e->sample_count;
+  A.cdf = e->d_cdf.p;
+  A.dst = ParticlesDev{ nullptr, nullptr, nullptr, nullptr };
+  A.m0 = m0;
+  A.m1 = m1;
+  A.rng_state = rng_state48;
+  A.jump = e->jump;
+  A.keys = e->d_keys.p;
+  A.src_index = e->d_src_index.p;
+  A.miss_flag = e->d_flags.p;
+  A.cdf_offset = cdf_offset;
+  A.sharded = 1;
+  A.is_last_shard = is_last_shard;
+  if (w > 0)
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(w, 256)), dim3(256), 0, e->stream, A);
+  }
+  HIPCHK(e, hipGetLastError());
+  std::vector<int> src((size_t)std::max(w, 1)), keys((size_t)std::max(w, 1) * 3);
+  HIPCHK(e, hipMemcpyAsync(src.data(), e->d_src_index.p, (size_t)w * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_keys.p, (size_t)w * 3 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->h_flags.p, e->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  // gather the selected poses on the host side of the shard (small: only this shard's hits)
+  std::vector<int> picked;
+  for (int o = 0; o < w; ++o)
+    if (src[o] >= 0)
+      picked.push_back(o);
+  if ((int)picked.size() > capacity)
+    return e->fail(BPF_ERR_CAPACITY, "draw_select output too small");
+  // poses: copy x/y/theta of the picked sources
+  std::vector<double> hx(e->sample_count), hy(e->sample_count), ht(e->sample_count);
+  if (!picked.empty())
+  {
+    HIPCHK(e, hipMemcpyAsync(hx.data(), a.x.p, (size_t)e->sample_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(hy.data(), a.y.p, (size_t)e->sample_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(ht.data(), a.th.p, (size_t)e->sample_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
+  for (size_t q = 0; q < picked.size(); ++q)
+  {
+    const int o = picked[q];
+    draw_index_out[q] = m0 + o;
+    poses_out[3 * q] = hx[src[o]];
+    poses_out[3 * q + 1] = hy[src[o]];
+    poses_out[3 * q + 2] = ht[src[o]];
+    keys_out[3 * q] = keys[3 * o];
+    keys_out[3 * q + 1] = keys[3 * o + 1];
+    keys_out[3 * q + 2] = keys[3 * o + 2];
+  }
+  *count_out = (int)picked.size();
+  if (miss_out)
+    *miss_out = e->h_flags.p[0];
+  return BPF_OK;
+}
+
+int bpf_kld_reset(bpf_engine* e)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->hist.clear();
+  return BPF_OK;
+}
+
+int bpf_kld_feed(bpf_engine* e, const int* keys, int n_keys, int first_draw_index, int* stop_count_out)
+{
+  if (!e || !keys || !stop_count_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  *stop_count_out = -1;
+  for (int q = 0; q < n_keys; ++q)
+  {
+    e->hist.insert(keys[3 * q], keys[3 * q + 1], keys[3 * q + 2]);
+    const int count = first_draw_index + q + 1;
+    if (count > resample_limit(e->hist.leaf_count(), e->min_samples, e->max_samples, e->pop_err, e->pop_z))
+    {
+      *stop_count_out = count;
+      break;
+    }
+  }
+  return BPF_OK;
+}
+
+int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (leaf_count_out)
+    *leaf_count_out = e->hist.leaf_count();
+  if (bin_count_out)
+    *bin_count_out = e->hist.bin_count();
+  return BPF_OK;
+}
+
+int bpf_set_option(bpf_engine* e, int option, int value)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (option == BPF_OPT_CDF_SERIAL)
+    e->cdf_serial = value != 0;
+  else if (option == BPF_OPT_COUNT_CELLS)
+    e->count_cells = value != 0;
+  else
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown option");
+  return BPF_OK;
+}
+
+int bpf_get_cells_walked(bpf_engine* e, unsigned long long* out, int reset)
+{
+  if (!e || !out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  *out = 0;
+  if (!e->d_cells_walked.p)
+    return BPF_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(out, e->d_cells_walked.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (reset)
+    HIPCHK(e, hipMemsetAsync(e->d_cells_walked.p, 0, sizeof(unsigned long long), e->stream));
+  return BPF_OK;
+}
+
+// ---------------------------------------------------------------------- measurement
+int bpf_profile_enable(bpf_engine* e, int on)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (on && e->ev_start.empty())
+  {
+    e->ev_start.resize(kEventPool);
+    e->ev_stop.resize(kEventPool);
+    e->ev_class.assign(kEventPool, 0);
+    for (int i = 0; i < kEventPool; ++i)
+    {
+      HIPCHK(e, hipEventCreate(&e->ev_start[i]));
+      HIPCHK(e, hipEventCreate(&e->ev_stop[i]));
+    }
+  }
+  e->profiling = on != 0;
+  return BPF_OK;
+}
+
+static int drain_events(bpf_engine* e)
+{
+  if (e->ev_used == 0)
+    return BPF_OK;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (size_t i = 0; i < e->ev_used; ++i)
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev_start[i], e->ev_stop[i]) == hipSuccess)
+    {
+      e->prof.ms[e->ev_class[i]] += ms;
+      e->prof.launches[e->ev_class[i]] += 1;
+    }
+  }
+  e->ev_used = 0;
+  return BPF_OK;
+}
+
+int bpf_profile_reset(bpf_engine* e)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  int rc = drain_events(e);
+  std::memset(&e->prof, 0, sizeof(e->prof));
+  return rc;
+}
+
+int bpf_profile_get(bpf_engine* e, bpf_profile* out)
+{
+  if (!e || !out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  int rc = drain_events(e);
+  *out = e->prof;
+  return rc;
+}
+
+const char* bpf_score_kernel_name(const bpf_engine* e)
+{
+  if (e && e->pm.model == BPF_MODEL_BEAM)
+    return "k_score_beam";
+  return "k_score_field";
+}
+
+}  // extern "C"

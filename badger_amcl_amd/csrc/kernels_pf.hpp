@@ -1,0 +1,477 @@
+// Particle-filter kernels: weight total / normalisation, CDF, drand48 draws + CDF search +
+// pose gather + histogram keys, systematic targets, convergence test, layout conversion,
+// distance-LUT construction.
+#pragma once
+#include "device_types.hpp"
+#include "kernels_score.hpp"
+
+namespace bpf
+{
+
+// ------------------------------------------------------------------ layout conversion
+// PFSample AoS {x,y,theta,w} (32 B) <-> SoA.  One thread per particle; the AoS side moves
+// as two 16-byte accesses per lane.
+__global__ void k_aos_to_soa(const double4* __restrict__ aos, ParticlesDev p, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const double4 v = aos[i];
+  p.x[i] = v.x;
+  p.y[i] = v.y;
+  p.th[i] = v.z;
+  p.w[i] = v.w;
+}
+
+__global__ void k_soa_to_aos(ParticlesDev p, double4* __restrict__ aos, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  aos[i] = make_double4(p.x[i], p.y[i], p.th[i], p.w[i]);
+}
+
+__global__ void k_fill(double* __restrict__ dst, double value, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    dst[i] = value;
+}
+
+// ------------------------------------------------------------------ deterministic sum
+// Fixed-shape two-level tree: block b sums elements b*2048 .. +2047 (thread t takes 8
+// consecutive ones), then one block folds the partials.  Same shape every run, so the
+// total is reproducible bit for bit (the reference sums serially, planar_scanner.cpp:679;
+// the difference is rounding only).
+#define BPF_RED_BLOCK 256
+#define BPF_RED_PER_THREAD 8
+#define BPF_RED_TILE (BPF_RED_BLOCK * BPF_RED_PER_THREAD)
+
+__device__ __forceinline__ double block_sum_256(double v, double* s_wave)
+{
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    s_wave[wave] = v;
+  __syncthreads();
+  const double r = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_sum_partials(const double* __restrict__ w, int n,
+                                                               double* __restrict__ partials)
+{
+  __shared__ double s_wave[4];
+  const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+    if (base + k < (size_t)n)
+      acc += w[base + k];
+  const double tot = block_sum_256(acc, s_wave);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = tot;
+}
+
+// scalars block layout (double[16]):
+//  [0] total of the last sensor update (local shard)   [1] w_slow  [2] w_fast
+//  [3] mean x   [4] mean y   [5] converged-count (as double)   [6] total used to normalise
+struct FilterScalars
+{
+  double v[16];
+};
+
+// Folds the partials; when update_averages != 0 also applies particle_filter.cpp:237-256:
+// w_avg = total / n, first-time assignment or exponential update of w_slow / w_fast.
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_sum_final(const double* __restrict__ partials, int n_partials,
+                                                            FilterScalars* sc, int slot, int update_averages,
+                                                            int n_samples, double alpha_slow, double alpha_fast)
+{
+  __shared__ double s_wave[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += BPF_RED_BLOCK)
+    acc += partials[i];
+  const double tot = block_sum_256(acc, s_wave);
+  if (threadIdx.x == 0)
+  {
+    sc->v[slot] = tot;
+    if (update_averages)
+    {
+      sc->v[6] = tot;
+      if (tot > 0.0)
+      {
+        const double w_avg = tot / n_samples;
+        double ws = sc->v[1], wf = sc->v[2];
+        if (ws == 0.0)
+          ws = w_avg;
+        else
+          ws += alpha_slow * (w_avg - ws);
+        if (wf == 0.0)
+          wf = w_avg;
+        else
+          wf += alpha_fast * (w_avg - wf);
+        sc->v[1] = ws;
+        sc->v[2] = wf;
+      }
+    }
+  }
+}
+
+// particle_filter.cpp:241-246 / :258-266.  total comes from device memory (slot 6) unless
+// use_host_total is set (sharded operation: the global total).
+__global__ void k_normalize(double* __restrict__ w, int n, const FilterScalars* sc, int use_host_total,
+                            double host_total, int global_n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const double total = use_host_total ? host_total : sc->v[6];
+  if (total > 0.0)
+    w[i] = w[i] / total;
+  else
+    w[i] = 1.0 / global_n;
+}
+
+// ------------------------------------------------------------------ CDF (inclusive scan)
+// c[0] = 0, c[i+1] = c[i] + w[i]  (particle_filter.cpp:372-375), evaluated as a fixed-shape
+// three-phase scan: per-2048-tile sums, scan of the tile sums by one block, then the
+// in-tile prefix.  Rounding differs from the reference's serial chain by a few ulp of the
+// running sum; see DESIGN.md "CDF edges".
+__device__ __forceinline__ double wave_incl_scan(double v)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const double o = __shfl_up(v, off, 64);
+    if (lane >= off)
+      v += o;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_tile_offsets(double* __restrict__ partials, int n_partials)
+{
+  // exclusive scan of the tile sums in place, serial per 256-chunk carry; n_partials is small
+  __shared__ double s_wave[4];
+  __shared__ double s_carry;
+  if (threadIdx.x == 0)
+    s_carry = 0.0;
+  __syncthreads();
+  for (int base = 0; base < n_partials; base += BPF_RED_BLOCK)
+  {
+    const int i = base + threadIdx.x;
+    const double v = (i < n_partials) ? partials[i] : 0.0;
+    const double incl = wave_incl_scan(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63)
+      s_wave[wave] = incl;
+    __syncthreads();
+    double wave_off = 0.0;
+    for (int k = 0; k < wave; ++k)
+      wave_off += s_wave[k];
+    const double carry = s_carry;
+    if (i < n_partials)
+      partials[i] = carry + (wave_off + (incl - v));
+    __syncthreads();
+    if (threadIdx.x == BPF_RED_BLOCK - 1)
+      s_carry = carry + (wave_off + incl);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __restrict__ w, int n,
+                                                             const double* __restrict__ tile_offsets,
+                                                             double* __restrict__ cdf)
+{
+  __shared__ double s_wave[4];
+  const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
+  double v[BPF_RED_PER_THREAD];
+  double run = 0.0;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+  {
+    const double x = (base + k < (size_t)n) ? w[base + k] : 0.0;
+    run += x;
+    v[k] = run;
+  }
+  const double incl = wave_incl_scan(run);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 63)
+    s_wave[wave] = incl;
+  __syncthreads();
+  double off = tile_offsets[blockIdx.x];
+  for (int k = 0; k < wave; ++k)
+    off += s_wave[k];
+  off += incl - run;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+    if (base + k < (size_t)n)
+      cdf[base + k + 1] = off + v[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    cdf[0] = 0.0;
+}
+
+// Strict variant: the reference's serial chain, one lane.  Bit-exact, O(n) latency-bound;
+// used by the parity tests (BPF_CDF_SERIAL) and as ground truth for the parallel scan.
+__global__ void k_scan_serial(const double* __restrict__ w, int n, double* __restrict__ cdf)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0)
+    return;
+  double c = 0.0;
+  cdf[0] = c;
+  for (int i = 0; i < n; ++i)
+  {
+    c = c + w[i];
+    cdf[i + 1] = c;
+  }
+}
+
+// ------------------------------------------------------------------ drand48 + selection
+__device__ __forceinline__ uint64_t lcg_skip(uint64_t x0, uint64_t n, const LcgJump& J)
+{
+  const uint64_t mask = (1ull << 48) - 1;
+  uint64_t a = 1, c = 0;
+  for (int j = 0; n != 0 && j < 48; ++j, n >>= 1)
+    if (n & 1)
+    {
+      // compose: x -> A_j*(a*x + c) + C_j
+      a = (a * J.A[j]) & mask;
+      c = (c * J.A[j] + J.C[j]) & mask;
+    }
+  return (a * x0 + c) & mask;
+}
+
+// first i with c[i] <= r < c[i+1] (particle_filter.cpp:394-398) by bisection; n on a miss
+__device__ __forceinline__ int cdf_find(const double* __restrict__ c, int n, double r)
+{
+  if (!(r < c[n]) || !(c[0] <= r))
+    return n;
+  int lo = 0, hi = n;
+  while (hi - lo > 1)
+  {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (c[mid] <= r)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// PFKDTree::insertPose key (pf_kdtree.cpp:52-54): floor(pose / {0.5, 0.5, 10 deg})
+__device__ __forceinline__ void pose_key(double x, double y, double th, int* key)
+{
+  const double cell_th = 10 * 3.14159265358979323846 / 180;
+  key[0] = (int)floor(x / 0.50);
+  key[1] = (int)floor(y / 0.50);
+  key[2] = (int)floor(th / cell_th);
+}
+
+struct DrawArgs
+{
+  ParticlesDev src;      // set a
+  int n_src;
+  const double* cdf;     // n_src + 1 (local shard CDF, starting at 0)
+  ParticlesDev dst;      // set b (nullable x => no pose scatter)
+  int m0, m1;            // global draw indices handled by this launch
+  uint64_t rng_state;    // 48-bit state before draw 0
+  LcgJump jump;
+  int* keys;             // [3*(m - m0)]
+  int* src_index;        // [m - m0]
+  int* miss_flag;        // set to 1 when a search misses (reference ROS_ASSERT)
+  // sharded selection: only draws with cdf_offset <= r < cdf_offset + c[n] belong here
+  double cdf_offset;
+  int sharded;
+  int is_last_shard;
+};
+
+// Multinomial resampler body for w_diff == 0 (particle_filter.cpp:381-414): draw m consumes
+// stream elements 2m+1 (compared with w_diff) and 2m+2 (r).
+__global__ void k_draw_select(const DrawArgs A)
+{
+  const int m = A.m0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= A.m1)
+    return;
+  const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
+  double r = ldexp((double)xs, -48);
+  const int o = m - A.m0;
+  int i;
+  if (A.sharded)
+  {
+    const double top = A.cdf_offset + A.cdf[A.n_src];
+    const bool mine = (r >= A.cdf_offset) && (r < top || A.is_last_shard);
+    if (!mine)
+    {
+      A.src_index[o] = -1;
+      return;
+    }
+    // search on the shifted CDF: c_global[i] = cdf_offset + c_local[i]
+    int lo = 0, hi = A.n_src;
+    if (!(r < top))
+    {
+      atomicExch(A.miss_flag, 1);
+      i = A.n_src - 1;
+    }
+    else
+    {
+      while (hi - lo > 1)
+      {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (A.cdf_offset + A.cdf[mid] <= r)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      i = lo;
+    }
+  }
+  else
+  {
+    i = cdf_find(A.cdf, A.n_src, r);
+    if (i >= A.n_src)
+    {
+      atomicExch(A.miss_flag, 1);
+      i = A.n_src - 1;
+    }
+  }
+  const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
+  if (A.dst.x != nullptr)
+  {
+    A.dst.x[m] = x;
+    A.dst.y[m] = y;
+    A.dst.th[m] = th;
+  }
+  A.src_index[o] = i;
+  pose_key(x, y, th, &A.keys[3 * o]);
+}
+
+// Systematic resampler targets (particle_filter.cpp:326-341): target_0 = start, then
+// target += delta; if (target > 1) target -= 1 -- a serial floating-point chain, kept serial
+// (one lane) so every target carries the reference's rounding.
+__global__ void k_systematic_targets(double start, double delta, int count, double* __restrict__ targets)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0)
+    return;
+  double t = start;
+  for (int i = 0; i < count; ++i)
+  {
+    targets[i] = t;
+    t += delta;
+    if (t > 1.0)
+      t -= 1.0;
+  }
+}
+
+struct SystematicArgs
+{
+  ParticlesDev src;
+  int n_src;
+  const double* cdf;
+  const double* targets;
+  ParticlesDev dst;
+  int count;
+  int* keys;
+  int* src_index;
+  int* miss_flag;
+};
+
+// The reference walks the CDF cyclically from the previous hit (particle_filter.cpp:329-336);
+// the interval that contains a target is unique, so each target is resolved independently.
+__global__ void k_systematic_select(const SystematicArgs A)
+{
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= A.count)
+    return;
+  int i = cdf_find(A.cdf, A.n_src, A.targets[m]);
+  if (i >= A.n_src)
+  {
+    atomicExch(A.miss_flag, 1);  // the reference never leaves its while loop here
+    i = A.n_src - 1;
+  }
+  const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
+  A.dst.x[m] = x;
+  A.dst.y[m] = y;
+  A.dst.th[m] = th;
+  A.src_index[m] = i;
+  pose_key(x, y, th, &A.keys[3 * m]);
+}
+
+__global__ void k_pose_keys(ParticlesDev p, int n, int* __restrict__ keys)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    pose_key(p.x[i], p.y[i], p.th[i], &keys[3 * i]);
+}
+
+// ------------------------------------------------------------------ updateConverged
+// particle_filter.cpp:170-220: mean x / y, then the count of particles within
+// dist_threshold of the mean on both axes.
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_count_converged(const double* __restrict__ x,
+                                                                  const double* __restrict__ y, int n,
+                                                                  const FilterScalars* sc, double thr,
+                                                                  int* __restrict__ count)
+{
+  __shared__ int s_cnt[4];
+  const double mx = sc->v[3] / n, my = sc->v[4] / n;
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (fabs(x[i] - mx) <= thr && fabs(y[i] - my) <= thr)
+      c++;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    c += __shfl_xor(c, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    s_cnt[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(count, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+}
+
+// ------------------------------------------------------------------ distance LUT (exact EDT)
+// Separable capped Euclidean distance transform on the reference's integer lattice:
+// value = float(sqrt(a^2+b^2) * res) for the nearest occupied cell if sqrt(a^2+b^2) <= radius,
+// else float(max_dist)   (value lattice of occupancy_map.cpp:122-135,227-245).
+__global__ void k_edt_rows(const int8_t* __restrict__ cells, int sx, int sy, int radius, int* __restrict__ dxrow)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= sx || y >= sy)
+    return;
+  int best = radius + 1;
+  for (int d = 0; d <= radius && d < best; ++d)
+  {
+    const int xl = x - d, xr = x + d;
+    if ((xl >= 0 && cells[xl + (size_t)y * sx] == 1) || (xr < sx && cells[xr + (size_t)y * sx] == 1))
+      best = d;
+  }
+  dxrow[x + (size_t)y * sx] = best;
+}
+
+__global__ void k_edt_cols(const int* __restrict__ dxrow, int sx, int sy, int radius, double res, double max_dist,
+                           float* __restrict__ lut)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= sx || y >= sy)
+    return;
+  const int r2 = radius * radius;
+  int best = r2 + 1;
+  for (int d = -radius; d <= radius; ++d)
+  {
+    const int yy = y + d;
+    if (yy < 0 || yy >= sy)
+      continue;
+    const int a = dxrow[x + (size_t)yy * sx];
+    if (a > radius)
+      continue;
+    const int v = a * a + d * d;
+    if (v < best)
+      best = v;
+  }
+  lut[x + (size_t)y * sx] = (best <= r2) ? (float)(sqrt((double)best) * res) : (float)max_dist;
+}
+
+}  // namespace bpf

@@ -1,0 +1,343 @@
+// Sensor scoring kernels (gfx950, wave64).
+//
+// Work mapping, both kernels: one wavefront scores one particle at a time with its 64
+// lanes striding over the beams -- consecutive beams of one particle end on neighbouring
+// map cells, so a wave's gathers fall into a handful of 8x8-cell tiles whatever the wall
+// orientation.  A wave takes 16 particles per trip: lanes 0..15 do the per-particle
+// trigonometry once, the results are broadcast through SGPRs (v_readlane), and the
+// per-particle sums come back to lanes 0..15 for the epilogue (weight update +
+// recalcWeight), which stores 16 consecutive weights.
+#pragma once
+#include "device_types.hpp"
+
+namespace bpf
+{
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// broadcast a double from a wave-uniform lane index through scalar registers
+__device__ __forceinline__ double lane_bcast(double v, int src_lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// angles::normalize_angle (third-party ROS `angles` header, Noetic form): fmod(a+pi, 2pi), <=0 ? +pi : -pi
+__device__ __forceinline__ double normalize_angle_dev(double a)
+{
+  const double kPi = 3.14159265358979323846;
+  const double r = fmod(a + kPi, 2.0 * kPi);
+  return (r <= 0.0) ? r + kPi : r - kPi;
+}
+
+// OccupancyMap::convertWorldToMap for one axis (occupancy_map.cpp:96-97), exact division
+__device__ __forceinline__ int world_to_cell(double v, double origin, double res, int half)
+{
+  const double f = floor((v - origin) / res + 0.5);
+  // v_cvt_i32_f64 saturates and maps NaN to 0; send NaN off the map like x86's INT_MIN does
+  return (f == f) ? (int)f + half : -1;
+}
+
+// PlanarScanner::recalcWeight for one particle (planar_scanner.cpp:642-682)
+__device__ __forceinline__ double recalc_factor(const MapDev& m, double px, double py, double off_map_factor,
+                                                double non_free_factor, double non_free_radius)
+{
+  const int ci = world_to_cell(px, m.origin_x, m.resolution, m.half_x);
+  const int cj = world_to_cell(py, m.origin_y, m.resolution, m.half_y);
+  if (!((unsigned)ci < (unsigned)m.size_x && (unsigned)cj < (unsigned)m.size_y))
+    return off_map_factor;
+  if (m.cells8[ci + (size_t)cj * m.size_x] != -1)
+    return non_free_factor;
+  const unsigned tile = (unsigned)(cj >> 3) * m.tiles_x + (ci >> 3);
+  const unsigned idx = m.lut_tiles[(size_t)tile * 64 + ((cj & 7) << 3) + (ci & 7)];
+  const double d = (double)m.levels[idx];
+  if (d < non_free_radius)
+  {
+    const double frac = d / non_free_radius;
+    double f = non_free_factor;
+    f += frac * (1.0 - non_free_factor);
+    return f;
+  }
+  return 1.0;
+}
+
+// scanner pose of a particle: PlanarScanner::coordAdd (planar_scanner.cpp:693-701)
+struct ScannerPose
+{
+  double x, y, c, s, th;
+};
+
+__device__ __forceinline__ ScannerPose scanner_pose(double px, double py, double pth, double ax, double ay,
+                                                    double ath)
+{
+  ScannerPose o;
+  double sn, cs;
+  sincos(pth, &sn, &cs);
+  o.x = px + ax * cs - ay * sn;
+  o.y = py + ax * sn + ay * cs;
+  o.th = normalize_angle_dev(pth + ath);
+  sincos(o.th, &o.s, &o.c);
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------
+// Likelihood-field family: calcLikelihoodFieldModel (planar_scanner.cpp:236-323),
+// calcLikelihoodFieldModelGompertz (:552-640) and the per-beam part of
+// calcLikelihoodFieldModelProb (:325-533).
+//
+// Per evaluation the reference computes cos/sin(theta + bearing), the end point, its cell,
+// the LUT distance z and a term f(z).  Here:
+//   * angle addition: the particle's (cos, sin) are computed once, the beam arrives as
+//     B = r*(cos b, sin b)/res, so the end point in cell units is 2 FMAs per axis;
+//   * z only takes the LUT's few hundred distinct float values ("levels"), so f(z) is a
+//     table indexed by the 16-bit level id of the cell, built on the host with the same
+//     libm expression as the reference (no transcendental in the loop, identical terms).
+// ---------------------------------------------------------------------------------------
+template <bool TABLE_IN_LDS>
+__global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* s_beams = reinterpret_cast<double2*>(smem);
+  double* s_table = reinterpret_cast<double*>(smem + (size_t)A.n_beams * sizeof(double2));
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < A.n_beams; i += 256)
+    s_beams[i] = A.beams[i];
+  if (TABLE_IN_LDS)
+    for (int i = tid; i < A.table_len; i += 256)
+      s_table[i] = A.table[i];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int sub = lane & 15;
+  const int wave = tid >> 6;
+  const int n_groups = (A.n + 15) >> 4;
+  const MapDev& M = A.map;
+  const unsigned off_map_level = (unsigned)M.n_levels;
+  const double* table = TABLE_IN_LDS ? s_table : A.table;
+
+  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4)
+  {
+    const int base = g << 4;
+    const int cnt = min(16, A.n - base);
+    const int pi = base + min(sub, cnt - 1);
+    const double px = A.p.x[pi], py = A.p.y[pi], pth = A.p.th[pi];
+    const ScannerPose sp = scanner_pose(px, py, pth, A.sp_x, A.sp_y, A.sp_th);
+    // end point in cell units: floor(Px + c*Bx - s*By) + half  (0.5 folded into Px)
+    const double Px = (sp.x - M.origin_x) / M.resolution + 0.5;
+    const double Py = (sp.y - M.origin_y) / M.resolution + 0.5;
+
+    double mine = 0.0;
+    for (int k = 0; k < cnt; ++k)
+    {
+      const double c = lane_bcast(sp.c, k), s = lane_bcast(sp.s, k);
+      const double qx = lane_bcast(Px, k), qy = lane_bcast(Py, k);
+      double acc = 0.0;
+      for (int b = lane; b < A.n_beams; b += 64)
+      {
+        const double2 B = s_beams[b];
+        const double vx = fma(c, B.x, fma(-s, B.y, qx));
+        const double vy = fma(s, B.x, fma(c, B.y, qy));
+        const double fx = floor(vx), fy = floor(vy);
+        const int ix = (fx == fx) ? (int)fx + M.half_x : -1;
+        const int iy = (fy == fy) ? (int)fy + M.half_y : -1;
+        const bool on_map = (unsigned)ix < (unsigned)M.size_x && (unsigned)iy < (unsigned)M.size_y;
+        unsigned level = off_map_level;
+        if (on_map)
+        {
+          const unsigned tile = (unsigned)(iy >> 3) * M.tiles_x + (ix >> 3);
+          level = M.lut_tiles[(size_t)tile * 64 + ((iy & 7) << 3) + (ix & 7)];
+        }
+        if (A.obs_count != nullptr && on_map && (int)level < A.skip_level)
+          atomicAdd(&A.obs_count[b], 1);
+        if (A.beam_mask == nullptr || A.beam_mask[b])
+          acc += table[level];
+      }
+      const double tot = wave_sum(acc);
+      if (sub == k)
+        mine = tot;
+    }
+
+    if (lane < cnt && !A.count_only)
+    {
+      double p;
+      if (A.model == 1)  // likelihood field: p = 1 + sum pz^3
+        p = 1.0 + mine;
+      else if (A.model == 3)  // Gompertz of the mean pz (planar_scanner.cpp:540-550,624-633)
+      {
+        if (A.n_beams > 0)
+        {
+          double v = mine / A.n_beams;
+          v = v * A.g.input_scale + A.g.input_shift;
+          v = A.g.a * exp(-1.0 * A.g.b * exp(-1.0 * A.g.c * v));
+          p = v + A.g.output_shift;
+        }
+        else
+          p = 1.0;
+      }
+      else  // prob: exp(sum log pz)
+        p = exp(mine);
+      const int q = base + lane;
+      double w = A.p.w[q] * p;
+      w *= recalc_factor(M, px, py, A.off_map_factor, A.non_free_factor, A.non_free_radius);
+      A.p.w[q] = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Beam model: calcBeamModel (planar_scanner.cpp:168-234) with OccupancyMap::calcRange
+// (occupancy_map.cpp:257-364).  The Bresenham walk reads the 1-bit "not free" grid in 8x8
+// tiles: a 64-bit word covers up to 8 steps in any direction and is re-fetched only when
+// the ray enters another tile.
+// ---------------------------------------------------------------------------------------
+struct BeamRec
+{
+  double cb, sb;   // cos / sin of the bearing
+  double obs;      // observed range
+  double short_t;  // z_short*lambda*exp(-lambda*obs)
+  double tail_t;   // z_max (obs == range_max) or z_rand/range_max (obs < range_max) or 0
+};
+
+__device__ __forceinline__ bool cell_blocked(const MapDev& M, int cx, int cy, int& cur_tile, uint64_t& bits)
+{
+  if (!((unsigned)cx < (unsigned)M.size_x && (unsigned)cy < (unsigned)M.size_y))
+    return true;
+  const int tile = (cy >> 3) * M.tiles_x + (cx >> 3);
+  if (tile != cur_tile)
+  {
+    bits = M.notfree_tiles[tile];
+    cur_tile = tile;
+  }
+  return (bits >> (((cy & 7) << 3) | (cx & 7))) & 1ull;
+}
+
+struct BeamModelArgs
+{
+  ParticlesDev p;
+  int n;
+  const BeamRec* beams;
+  int n_beams;
+  MapDev map;
+  double sp_x, sp_y, sp_th;
+  double off_map_factor, non_free_factor, non_free_radius;
+  double range_max, z_hit, denom;
+  unsigned long long* cells_walked;
+};
+
+__global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  BeamRec* s_beams = reinterpret_cast<BeamRec*>(smem);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < A.n_beams; i += 256)
+    s_beams[i] = A.beams[i];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int sub = lane & 15;
+  const int wave = tid >> 6;
+  const int n_groups = (A.n + 15) >> 4;
+  const MapDev& M = A.map;
+  unsigned long long walked = 0;
+
+  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4)
+  {
+    const int base = g << 4;
+    const int cnt = min(16, A.n - base);
+    const int pi = base + min(sub, cnt - 1);
+    const double px = A.p.x[pi], py = A.p.y[pi], pth = A.p.th[pi];
+    const ScannerPose sp = scanner_pose(px, py, pth, A.sp_x, A.sp_y, A.sp_th);
+    const int cx0 = world_to_cell(sp.x, M.origin_x, M.resolution, M.half_x);
+    const int cy0 = world_to_cell(sp.y, M.origin_y, M.resolution, M.half_y);
+
+    double mine = 0.0;
+    for (int k = 0; k < cnt; ++k)
+    {
+      const double c = lane_bcast(sp.c, k), s = lane_bcast(sp.s, k);
+      const double ox = lane_bcast(sp.x, k), oy = lane_bcast(sp.y, k);
+      const int sx0 = __builtin_amdgcn_readlane(cx0, k), sy0 = __builtin_amdgcn_readlane(cy0, k);
+      double acc = 0.0;
+      for (int b = lane; b < A.n_beams; b += 64)
+      {
+        const BeamRec B = s_beams[b];
+        const double ca = c * B.cb - s * B.sb;  // cos(theta + bearing)
+        const double sa = s * B.cb + c * B.sb;
+        int x0 = sx0, y0 = sy0;
+        int x1 = world_to_cell(ox + A.range_max * ca, M.origin_x, M.resolution, M.half_x);
+        int y1 = world_to_cell(oy + A.range_max * sa, M.origin_y, M.resolution, M.half_y);
+        double map_range = A.range_max;
+        if (!(x0 == x1 && y0 == y1))
+        {
+          const bool steep = abs(y1 - y0) > abs(x1 - x0);
+          if (steep)
+          {
+            int t = x0; x0 = y0; y0 = t;
+            t = x1; x1 = y1; y1 = t;
+          }
+          const int dx = abs(x1 - x0), dy = abs(y1 - y0);
+          const int stx = (x0 < x1) ? 1 : -1, sty = (y0 < y1) ? 1 : -1;
+          int err = 0, x = x0, y = y0;
+          int cur_tile = -1;
+          uint64_t bits = 0;
+          // dx+2 cells at most: the reference walks to x1 + step inclusive
+          for (int it = 0; it <= dx + 1; ++it)
+          {
+            ++walked;
+            const bool hit = steep ? cell_blocked(M, y, x, cur_tile, bits) : cell_blocked(M, x, y, cur_tile, bits);
+            if (hit)
+            {
+              const int ddx = x - x0, ddy = y - y0;
+              map_range = sqrt((double)(ddx * ddx + ddy * ddy)) * M.resolution;
+              break;
+            }
+            x += stx;
+            err += dy;
+            if (2 * err >= dx)
+            {
+              y += sty;
+              err -= dx;
+            }
+          }
+        }
+        const double z = B.obs - map_range;
+        double pz = 0.0;
+        pz += A.z_hit * exp(-(z * z) / A.denom);
+        if (z < 0)
+          pz += B.short_t;
+        pz += B.tail_t;
+        acc += pz * pz * pz;
+      }
+      const double tot = wave_sum(acc);
+      if (sub == k)
+        mine = tot;
+    }
+
+    if (lane < cnt)
+    {
+      const int q = base + lane;
+      double w = A.p.w[q] * (1.0 + mine);
+      w *= recalc_factor(M, px, py, A.off_map_factor, A.non_free_factor, A.non_free_radius);
+      A.p.w[q] = w;
+    }
+  }
+  if (A.cells_walked != nullptr)
+  {
+    // per-wave total, one atomic per wave
+    unsigned long long wsum = walked;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      wsum += __shfl_xor(wsum, off, 64);
+    if (lane == 0)
+      atomicAdd(A.cells_walked, wsum);
+  }
+}
+
+}  // namespace bpf

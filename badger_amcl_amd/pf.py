@@ -1,0 +1,319 @@
+"""Host-side mirror of the reference interface for the hot path, on top of the C-ABI.
+
+Class and method names follow the reference (include/amcl/...): OccupancyMap,
+PlanarData, PlanarScanner, ParticleFilter -- so a parity test reads like the reference's
+own call sequence:
+
+    map = OccupancyMap(engine, resolution); map.setSize(...); map.setOrigin(...); ...
+    scanner = PlanarScanner(engine); scanner.init(max_beams, map)
+    scanner.setModelLikelihoodField(z_hit, z_rand, sigma_hit, max_dist)
+    pf = ParticleFilter(engine, min_samples, max_samples, alpha_slow, alpha_fast, thr)
+    scanner.updateSensor(pf, data); pf.updateResample()
+
+All computation happens in libbadger_pf_hip.so on the GPU.  This module only marshals.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+MODEL_BEAM, MODEL_LIKELIHOOD_FIELD, MODEL_LIKELIHOOD_FIELD_PROB, MODEL_LIKELIHOOD_FIELD_GOMPERTZ = 0, 1, 2, 3
+PF_RESAMPLE_MULTINOMIAL, PF_RESAMPLE_SYSTEMATIC = 0, 1
+OPT_CDF_SERIAL, OPT_COUNT_CELLS = 0, 1
+CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
+
+
+class BpfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bpf error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Engine:
+    """One HIP engine = one GPU-resident map + scanner model + particle filter."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.bpf_create(device, C.byref(h))
+        if rc != 0:
+            raise BpfError(rc, "bpf_create failed (%s)" % self.lib.bpf_error_string(rc).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bpf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise BpfError(rc, self.lib.bpf_last_error_message(self.h).decode() or
+                           self.lib.bpf_error_string(rc).decode())
+
+    def set_stream(self, hip_stream):
+        self.check(self.lib.bpf_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self.check(self.lib.bpf_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.bpf_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self.check(self.lib.bpf_profile_reset(self.h))
+
+    def profile_get(self):
+        p = _lib.Profile()
+        self.check(self.lib.bpf_profile_get(self.h, C.byref(p)))
+        names = ["score", "reduce", "normalize", "cdf", "draw", "finalize", "k6", "k7"]
+        return {n: {"ms": p.ms[i], "launches": p.launches[i]} for i, n in enumerate(names)}
+
+    def set_option(self, option, value):
+        self.check(self.lib.bpf_set_option(self.h, option, int(value)))
+
+    def cells_walked(self, reset=True):
+        v = C.c_ulonglong()
+        self.check(self.lib.bpf_get_cells_walked(self.h, C.byref(v), int(reset)))
+        return v.value
+
+    def score_kernel_name(self):
+        return self.lib.bpf_score_kernel_name(self.h).decode()
+
+
+class OccupancyMap:
+    """include/amcl/map/occupancy_map.h:54-123 (state only; queries run on the GPU)."""
+
+    def __init__(self, engine, resolution):
+        self.e = engine
+        self.resolution = float(resolution)
+        self.size_x = self.size_y = 0
+        self.origin = (np.float32(0), np.float32(0))
+        self.cells = None
+        self.max_distance_to_object = 0.0
+        self.lut = None
+        self._dirty = True
+
+    def setSize(self, size_vec):
+        self.size_x, self.size_y = int(size_vec[0]), int(size_vec[1])
+        self.cells = np.zeros((self.size_y, self.size_x), dtype=np.int32)
+        self._dirty = True
+
+    def getSize(self):
+        return [self.size_x, self.size_y]
+
+    def setOrigin(self, origin_xy):
+        self.origin = (np.float32(origin_xy[0]), np.float32(origin_xy[1]))  # pcl::PointXYZ is float
+        self._dirty = True
+
+    def computeCellIndex(self, i, j):
+        return i + j * self.size_x
+
+    def setCellState(self, index, state):
+        self.cells.reshape(-1)[index] = state
+        self._dirty = True
+
+    def setCells(self, cells):
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self.size_y, self.size_x = cells.shape
+        self.cells = cells
+        self._dirty = True
+
+    def setDistancesLUT(self, lut, max_distance_to_object):
+        """Adopt a host-built distances_lut_ (e.g. the reference's brushfire output)."""
+        self.lut = np.ascontiguousarray(lut, dtype=np.float32)
+        self.max_distance_to_object = float(max_distance_to_object)
+        self._dirty = True
+
+    def upload(self):
+        if not self._dirty:
+            return
+        lutp = self.lut.ctypes.data_as(C.POINTER(C.c_float)) if self.lut is not None else None
+        self.e.check(self.e.lib.bpf_map2d_set(self.e.h, self.cells.ctypes.data_as(C.POINTER(C.c_int32)), lutp,
+                                              self.size_x, self.size_y, float(self.origin[0]), float(self.origin[1]),
+                                              self.resolution, self.max_distance_to_object))
+        self._dirty = False
+
+    def updateDistancesLUT(self, max_distance_to_object):
+        """Device EDT (exact); differs from the reference's approximate brushfire in a few cells."""
+        self.upload()
+        self.e.check(self.e.lib.bpf_map2d_build_distances_lut(self.e.h, float(max_distance_to_object)))
+        self.max_distance_to_object = float(max_distance_to_object)
+        self.lut = None
+
+    def getDistancesLUT(self):
+        out = np.zeros((self.size_y, self.size_x), dtype=np.float32)
+        self.e.check(self.e.lib.bpf_map2d_get_distances_lut(self.e.h, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                            out.size))
+        return out
+
+
+class PlanarData:
+    """include/amcl/sensors/planar_scanner.h:45-54"""
+
+    def __init__(self, ranges, angles, range_max):
+        self.ranges_ = np.ascontiguousarray(ranges, dtype=np.float64)
+        self.angles_ = np.ascontiguousarray(angles, dtype=np.float64)
+        self.range_count_ = int(self.ranges_.shape[0])
+        self.range_max_ = float(range_max)
+
+
+class PFSampleSet:
+    """View of the current sample set copied to the host (particle_filter.h:70-87)."""
+
+    def __init__(self, samples, state):
+        self.samples = samples  # [N,4] x, y, theta, weight
+        self.sample_count = state.sample_count
+        self.converged = state.converged
+        self.leaf_count = state.leaf_count
+
+
+class ParticleFilter:
+    """include/amcl/pf/particle_filter.h:92-184 on the GPU-resident set."""
+
+    def __init__(self, engine, min_samples, max_samples, alpha_slow, alpha_fast,
+                 global_localization_convergence_threshold, random_pose_fn=None):
+        self.e = engine
+        self.max_samples = max_samples
+        self.min_samples = min_samples
+        self.random_pose_fn = random_pose_fn
+        engine.check(engine.lib.bpf_pf_create(engine.h, min_samples, max_samples, alpha_slow, alpha_fast,
+                                              global_localization_convergence_threshold))
+
+    def setResampleModel(self, model):
+        self.e.check(self.e.lib.bpf_pf_set_resample_model(self.e.h, model))
+
+    def setPopulationSizeParameters(self, pop_err, pop_z):
+        self.e.check(self.e.lib.bpf_pf_set_population_size_parameters(self.e.h, pop_err, pop_z))
+
+    def setDecayRates(self, alpha_slow, alpha_fast):
+        self.e.check(self.e.lib.bpf_pf_set_decay_rates(self.e.h, alpha_slow, alpha_fast))
+
+    def srand48(self, seed):
+        self.e.check(self.e.lib.bpf_pf_srand48(self.e.h, seed))
+
+    def getRngState(self):
+        s = C.c_uint64()
+        self.e.check(self.e.lib.bpf_pf_get_rng_state(self.e.h, C.byref(s)))
+        return s.value
+
+    def setRngState(self, state):
+        self.e.check(self.e.lib.bpf_pf_set_rng_state(self.e.h, state))
+
+    def initWithSamples(self, samples, leaf_count=-1):
+        """What initWithPoseFn / initWithGaussian leave behind: poses + weights of the current set."""
+        s = np.ascontiguousarray(samples, dtype=np.float64)
+        assert s.ndim == 2 and s.shape[1] == 4
+        self.e.check(self.e.lib.bpf_pf_set_samples(self.e.h, _dp(s), s.shape[0], leaf_count))
+
+    def initWithPoseFn(self, pose_fn):
+        s = np.zeros((self.max_samples, 4), dtype=np.float64)
+        for i in range(self.max_samples):
+            s[i, :3] = pose_fn()
+        s[:, 3] = 1.0 / self.max_samples
+        self.initWithSamples(s)
+
+    def snapshot(self):
+        self.e.check(self.e.lib.bpf_pf_snapshot(self.e.h))
+
+    def restore(self):
+        self.e.check(self.e.lib.bpf_pf_restore(self.e.h))
+
+    def fillWeights(self, w):
+        self.e.check(self.e.lib.bpf_pf_fill_weights(self.e.h, w))
+
+    def updateResample(self):
+        self.e.check(self.e.lib.bpf_pf_update_resample(self.e.h))
+
+    def getState(self):
+        st = _lib.PFState()
+        self.e.check(self.e.lib.bpf_pf_get_state(self.e.h, C.byref(st)))
+        return st
+
+    def getCurrentSet(self):
+        st = self.getState()
+        out = np.zeros((self.max_samples, 4), dtype=np.float64)
+        n = C.c_int()
+        self.e.check(self.e.lib.bpf_pf_get_samples(self.e.h, _dp(out), self.max_samples, C.byref(n)))
+        return PFSampleSet(out[:n.value].copy(), st)
+
+    def isConverged(self):
+        return bool(self.getState().converged)
+
+
+class PlanarScanner:
+    """include/amcl/sensors/planar_scanner.h:57-168"""
+
+    def __init__(self, engine):
+        self.e = engine
+        self.max_beams = 0
+        self.map = None
+        engine.check(engine.lib.bpf_planar_set_map_factors(engine.h, 1.0, 1.0, 0.0))
+
+    def init(self, max_beams, occupancy_map):
+        self.max_beams = max_beams
+        self.map = occupancy_map
+        occupancy_map.upload()
+        self.e.check(self.e.lib.bpf_planar_init(self.e.h, max_beams))
+
+    def setModelBeam(self, z_hit, z_short, z_max, z_rand, sigma_hit, lambda_short):
+        self.map.upload()
+        self.e.check(self.e.lib.bpf_planar_set_model_beam(self.e.h, z_hit, z_short, z_max, z_rand, sigma_hit,
+                                                          lambda_short))
+
+    def setModelLikelihoodField(self, z_hit, z_rand, sigma_hit, max_distance_to_object):
+        self.map.upload()
+        self.e.check(self.e.lib.bpf_planar_set_model_likelihood_field(self.e.h, z_hit, z_rand, sigma_hit,
+                                                                      max_distance_to_object))
+
+    def setModelLikelihoodFieldProb(self, z_hit, z_rand, sigma_hit, max_distance_to_object, do_beamskip,
+                                    beam_skip_distance, beam_skip_threshold, beam_skip_error_threshold):
+        self.map.upload()
+        self.e.check(self.e.lib.bpf_planar_set_model_likelihood_field_prob(
+            self.e.h, z_hit, z_rand, sigma_hit, max_distance_to_object, int(do_beamskip), beam_skip_distance,
+            beam_skip_threshold, beam_skip_error_threshold))
+
+    def setModelLikelihoodFieldGompertz(self, z_hit, z_rand, sigma_hit, max_distance_to_object, gompertz_a,
+                                        gompertz_b, gompertz_c, input_shift, input_scale, output_shift):
+        self.map.upload()
+        self.e.check(self.e.lib.bpf_planar_set_model_likelihood_field_gompertz(
+            self.e.h, z_hit, z_rand, sigma_hit, max_distance_to_object, gompertz_a, gompertz_b, gompertz_c,
+            input_shift, input_scale, output_shift))
+
+    def setMapFactors(self, off_map_factor, non_free_space_factor, non_free_space_radius):
+        self.e.check(self.e.lib.bpf_planar_set_map_factors(self.e.h, off_map_factor, non_free_space_factor,
+                                                           non_free_space_radius))
+
+    def setPlanarScannerPose(self, scanner_pose):
+        p = np.ascontiguousarray(scanner_pose, dtype=np.float64)
+        self.e.check(self.e.lib.bpf_planar_set_scanner_pose(self.e.h, _dp(p)))
+
+    def updateSensor(self, pf, data):
+        """PlanarScanner::updateSensor(pf, data): false (and no effect) when max_beams < 2."""
+        if self.max_beams < 2:
+            return False
+        self.e.check(self.e.lib.bpf_pf_update_sensor_planar(self.e.h, _dp(data.ranges_), _dp(data.angles_),
+                                                            data.range_count_, data.range_max_))
+        return True
+
+    def applyModelToSampleSet(self, data, samples, set_converged=0):
+        """Seam A with host buffers: samples [N,4] float64, weights multiplied in place; returns total."""
+        assert samples.dtype == np.float64 and samples.flags.c_contiguous
+        status = C.c_int(0)
+        total = self.e.lib.bpf_planar_apply_model_to_sample_set(
+            self.e.h, _dp(samples), samples.shape[0], int(set_converged), _dp(data.ranges_), _dp(data.angles_),
+            data.range_count_, data.range_max_, C.byref(status))
+        if status.value != 0:
+            self.e.check(status.value)
+        return total

@@ -1,0 +1,102 @@
+"""Seeded synthetic inputs for the hot path: map, scan, particle clouds.
+
+Pure numpy input generation -- nothing here scores, normalises or resamples.  The same
+arrays are handed to the HIP engine and, in tests / the cpu_baseline leg, to the oracle.
+"""
+import math
+
+import numpy as np
+
+
+def make_map(size, resolution=0.05, seed=0):
+    """size x size tri-state grid: border walls, a lattice of wall segments, an unknown strip.
+    Returns (cells[int32, size_y x size_x], origin_xy) with the map spanning [0, size*res)^2,
+    i.e. origin = (size/2)*res narrowed to float32 like node_2d.cpp:275-277."""
+    s = int(size)
+    ys, xs = np.mgrid[0:s, 0:s]
+    cells = np.full((s, s), -1, dtype=np.int32)
+    wall = ((xs % 80 == 0) & (ys % 40 < 30)) | ((ys % 100 == 0) & (xs % 50 < 35))
+    wall |= (xs == 0) | (ys == 0) | (xs == s - 1) | (ys == s - 1)
+    # keep the neighbourhood of the map centre free so the true pose is in free space
+    c = s // 2
+    wall[max(c - 6, 1):c + 7, max(c - 6, 1):c + 7] = False
+    cells[wall] = 1
+    strip = (xs >= s // 3) & (xs < s // 3 + 3) & (ys > s // 8) & (ys < s // 8 + s // 5) & ~wall
+    cells[strip] = 0
+    origin = (np.float32((s // 2) * resolution), np.float32((s // 2) * resolution))
+    return cells, origin
+
+
+def true_pose(size, resolution=0.05):
+    c = (size // 2) * resolution
+    return np.array([c + 0.1, c + 0.0, 0.3], dtype=np.float64)
+
+
+def _world_to_cell(v, origin, res, half):
+    return np.floor((v - float(origin)) / res + 0.5).astype(np.int64) + half
+
+
+def cast_scan(cells, origin, resolution, pose, n_beams, range_max=30.0, fov=1.5 * math.pi, noise=0.01, seed=1,
+              frac_max=0.0, frac_nan=0.0):
+    """Ranges seen from `pose` by marching each ray in quarter-cell steps to the first
+    non-free or off-map cell (input generation only; not the reference's Bresenham)."""
+    rng = np.random.default_rng(seed)
+    sy, sx = cells.shape
+    angles = np.linspace(-fov / 2, fov / 2, n_beams)
+    step = resolution * 0.25
+    n_steps = int(range_max / step) + 1
+    ranges = np.full(n_beams, range_max, dtype=np.float64)
+    alive = np.ones(n_beams, dtype=bool)
+    ca, sa = np.cos(pose[2] + angles), np.sin(pose[2] + angles)
+    for k in range(1, n_steps):
+        if not alive.any():
+            break
+        d = k * step
+        ix = _world_to_cell(pose[0] + d * ca[alive], origin[0], resolution, sx // 2)
+        iy = _world_to_cell(pose[1] + d * sa[alive], origin[1], resolution, sy // 2)
+        inside = (ix >= 0) & (ix < sx) & (iy >= 0) & (iy < sy)
+        hit = ~inside
+        hit[inside] = cells[iy[inside], ix[inside]] != -1
+        idx = np.flatnonzero(alive)[hit]
+        ranges[idx] = d
+        alive[idx] = False
+    ranges = ranges + rng.normal(0.0, noise, n_beams)
+    ranges = np.clip(ranges, 0.05, np.nextafter(range_max, 0.0))
+    ranges = np.float32(ranges).astype(np.float64)  # LaserScan ranges are float32 (node_2d.cpp:549-559)
+    ranges = np.minimum(ranges, np.nextafter(range_max, 0.0))
+    if frac_max > 0:
+        ranges[rng.random(n_beams) < frac_max] = range_max
+    if frac_nan > 0:
+        ranges[rng.random(n_beams) < frac_nan] = np.nan
+    return ranges, angles.astype(np.float64)
+
+
+def converged_cloud(n, pose, seed=42, sigma=(0.3, 0.3, 0.1)):
+    rng = np.random.default_rng(seed)
+    s = np.zeros((n, 4), dtype=np.float64)
+    s[:, 0] = pose[0] + rng.normal(0, sigma[0], n)
+    s[:, 1] = pose[1] + rng.normal(0, sigma[1], n)
+    s[:, 2] = pose[2] + rng.normal(0, sigma[2], n)
+    s[:, 3] = 1.0 / n
+    return s
+
+
+def spread_cloud(n, size, resolution=0.05, seed=43, margin=-1.0):
+    """Uniform over the map (margin < 0 pushes some particles off the map edge)."""
+    rng = np.random.default_rng(seed)
+    extent = size * resolution
+    s = np.zeros((n, 4), dtype=np.float64)
+    s[:, 0] = rng.uniform(margin, extent - margin, n)
+    s[:, 1] = rng.uniform(margin, extent - margin, n)
+    s[:, 2] = rng.uniform(-math.pi, math.pi, n)
+    s[:, 3] = 1.0 / n
+    return s
+
+
+# model parameter sets --------------------------------------------------------------
+LF_DEFAULTS = dict(z_hit=0.95, z_rand=0.05, sigma_hit=0.2)                       # node_2d.cpp:53-58
+BEAM_DEFAULTS = dict(z_hit=0.95, z_short=0.1, z_max=0.05, z_rand=0.05, sigma_hit=0.2, lambda_short=0.1)
+GOMPERTZ_LAUNCH = dict(z_hit=0.5, z_rand=0.5, sigma_hit=0.05, gompertz_a=0.941, gompertz_b=5.0, gompertz_c=3.0,
+                       input_shift=-0.97, input_scale=2.0, output_shift=0.25)    # badger_amcl_2d.launch:69-123
+MAP_FACTORS = (0.95, 0.95, 0.3)                                                   # badger_amcl_2d.launch:125-129
+SCANNER_POSE = (0.1, 0.0, 0.0)

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-beam evaluations per second over (sensor update + resample).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over the resident particle set:
+    restore the set (device-to-device, stands in for the motion update that rewrites every pose)
+    -> PlanarScanner::updateSensor (scoring + recalcWeight + normalise + running averages)
+    -> ParticleFilter::updateResample (CDF, drand48 draws, selection, KLD stop, weights 1/M).
+Workload at N=1: BASELINE.json configs[1] -- 2-D likelihood field, 100 000 particles x 1081
+beams, 2000x2000 map, converged cloud; inputs are resident in HBM before the
+timed region.  For N>1 the driver launches one rank per GPU through torch.distributed.run;
+each rank holds a 100 000-particle shard of one filter (weak scaling).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(model, n, beams, mean_cells=None):
+    """LF family 4 B/eval + 40 B/particle + 16 B/beam; beam model C x 1 B/eval."""
+    per_eval = 4.0 if model != "beam" else float(mean_cells or 0.0)
+    return per_eval * n * beams + 40.0 * n + 16.0 * beams
+
+
+def build_workload(args, rank):
+    from badger_amcl_amd import synth
+    size, beams, n = args.map_size, args.beams, args.particles
+    cells, origin = synth.make_map(size)
+    pose = synth.true_pose(size)
+    ranges, angles = synth.cast_scan(cells, origin, 0.05, pose, beams, seed=5)
+    if args.cloud == "converged":
+        samples = synth.converged_cloud(n, pose, seed=42 + rank)
+    else:
+        samples = synth.spread_cloud(n, size, seed=43 + rank, margin=0.5)
+    return dict(cells=cells, origin=origin, pose=pose, ranges=ranges, angles=angles, samples=samples,
+                size=size, beams=beams, n=n)
+
+
+def setup_engine(args, wl, device):
+    import badger_amcl_amd as bpf
+    from badger_amcl_amd import synth
+    e = bpf.Engine(device)
+    m = bpf.OccupancyMap(e, 0.05)
+    m.setCells(wl["cells"])
+    m.setOrigin(wl["origin"])
+    m.updateDistancesLUT(2.0)
+    sc = bpf.PlanarScanner(e)
+    sc.init(wl["beams"], m)
+    if args.model == "lf":
+        p = synth.LF_DEFAULTS
+        sc.setModelLikelihoodField(p["z_hit"], p["z_rand"], p["sigma_hit"], 2.0)
+    elif args.model == "gompertz":
+        p = synth.GOMPERTZ_LAUNCH
+        sc.setModelLikelihoodFieldGompertz(p["z_hit"], p["z_rand"], p["sigma_hit"], 2.0, p["gompertz_a"],
+                                           p["gompertz_b"], p["gompertz_c"], p["input_shift"], p["input_scale"],
+                                           p["output_shift"])
+    else:
+        p = synth.BEAM_DEFAULTS
+        sc.setModelBeam(p["z_hit"], p["z_short"], p["z_max"], p["z_rand"], p["sigma_hit"], p["lambda_short"])
+    sc.setMapFactors(*synth.MAP_FACTORS)
+    sc.setPlanarScannerPose(synth.SCANNER_POSE)
+    pf = bpf.ParticleFilter(e, 100, wl["n"], 0.0, 0.0, 85.0)
+    pf.setResampleModel(1 if args.resampler == "systematic" else 0)
+    pf.srand48(42)
+    pf.initWithSamples(wl["samples"])
+    pf.snapshot()
+    data = bpf.PlanarData(wl["ranges"], wl["angles"], 30.0)
+    lut = m.getDistancesLUT()
+    return e, m, sc, pf, data, lut
+
+
+def cpu_baseline(args, wl, lut, budget_s):
+    """The oracle (a port of the reference's CPU path) timed on this box's host cores: 1 thread,
+    same workload, as many whole steps as fit the budget (at least one)."""
+    from badger_amcl_amd import synth
+    from oracle import pyoracle as orc
+    omap = orc.OccupancyMap(wl["cells"], 0.05, wl["origin"], 2.0, lut)
+    if args.model == "lf":
+        p = orc.planar(orc.MODEL_LF, wl["beams"], scanner_pose=synth.SCANNER_POSE, **synth.LF_DEFAULTS)
+    elif args.model == "gompertz":
+        p = orc.planar(orc.MODEL_LF_GOMPERTZ, wl["beams"], scanner_pose=synth.SCANNER_POSE, **synth.GOMPERTZ_LAUNCH)
+    else:
+        p = orc.planar(orc.MODEL_BEAM, wl["beams"], scanner_pose=synth.SCANNER_POSE, **synth.BEAM_DEFAULTS)
+    p.off_map_factor, p.non_free_space_factor, p.non_free_space_radius = synth.MAP_FACTORS
+    n = wl["n"]
+    n_cpu = n if args.model != "beam" else max(1000, n // 10)  # the raycast model is ~6x slower per eval
+    steps, t_used, stats = 0, 0.0, {}
+    last = None
+    while steps == 0 or (t_used < budget_s and t_used / steps * (steps + 1) < budget_s * 1.5):
+        opf = orc.ParticleFilter(100, n_cpu, 0.0, 0.0, 85.0, seed=42)
+        opf.set_resample_model(1 if args.resampler == "systematic" else 0)
+        opf.set_samples(wl["samples"][:n_cpu], leaf_count=0)
+        t0 = time.perf_counter()
+        opf.update_sensor(lambda s, conv: orc.planar_apply(p, omap, s, wl["ranges"], wl["angles"], 30.0, conv, stats))
+        out = opf.update_resample()
+        t_used += time.perf_counter() - t0
+        steps += 1
+        last = out
+    evals = float(n_cpu) * wl["beams"] * steps
+    mean_cells = (stats.get("cells", 0) / stats["evals"]) if stats.get("evals") else None
+    return dict(value=evals / t_used, unit="particle-beam evals/s", cores=1, kind="port",
+                sample="%d step(s) of %d particles x %d beams (%s, %s cloud, %s resampling), %.1f s, oracle "
+                       "gcc -O2 single thread; resampled to M=%d" % (steps, n_cpu, wl["beams"], args.model, args.cloud,
+                                                                     args.resampler, t_used, last.sample_count)), \
+        mean_cells, opf
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="lf", choices=["lf", "gompertz", "beam"])
+    ap.add_argument("--cloud", default="converged", choices=["converged", "spread"])
+    ap.add_argument("--resampler", default="multinomial", choices=["multinomial", "systematic"])
+    ap.add_argument("--particles", type=int, default=100000, help="particles per GPU")
+    ap.add_argument("--beams", type=int, default=1081)
+    ap.add_argument("--map-size", type=int, default=2000)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    wl = build_workload(args, rank)
+    e, m, sc, pf, data, lut = setup_engine(args, wl, local_rank)
+
+    if world > 1:
+        from badger_amcl_amd.sharded import ShardedFilter
+        sf = ShardedFilter(e, sc, pf, dist, device=torch.device("cuda", local_rank))
+
+        def step():
+            pf.restore()
+            sf.update_sensor(data)
+            sf.update_resample()
+    else:
+        def step():
+            pf.restore()
+            sc.updateSensor(pf, data)
+            pf.updateResample()
+
+    def fence():
+        e.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        e.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    e.profile_enable(True)
+    e.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = e.profile_get()
+    e.profile_enable(False)
+    st = pf.getState() if world == 1 else sf.state()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    n_total = wl["n"] * world
+    evals_per_step = float(n_total) * wl["beams"]
+    value = evals_per_step * args.steps / dt
+
+    if rank == 0:
+        cpu, mean_cells = None, None
+        if world == 1 and args.cpu_budget > 0:
+            cpu, mean_cells, _ = cpu_baseline(args, wl, lut, args.cpu_budget)
+        score = prof["score"]
+        k_ms = score["ms"] / max(score["launches"], 1)
+        if args.model == "beam":
+            e.set_option(1, 1)
+            e.cells_walked(reset=True)
+            pf.restore()
+            sc.updateSensor(pf, data)
+            e.synchronize()
+            mean_cells = e.cells_walked() / (float(wl["n"]) * wl["beams"])
+            e.set_option(1, 0)
+        abytes = algorithmic_bytes(args.model, wl["n"], wl["beams"], mean_cells)
+        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s_%s" % (args.model, args.cloud), {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "particle-beam evals/sec (sensor update+resample), 100k particles x 1081 beams",
+            "value": value, "unit": "particle-beam evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D likelihood-field, 100k particles, 1081 beams, 2000x2000 map"
+                       if (args.model, args.particles, args.beams, args.map_size) == ("lf", 100000, 1081, 2000)
+                       else "2D %s, %d particles/GPU, %d beams, %dx%d map" % (args.model, args.particles, args.beams,
+                                                                             args.map_size, args.map_size),
+                       "cloud": args.cloud, "resampler": args.resampler, "particles_per_gpu": wl["n"],
+                       "particles_total": n_total, "resampled_to": int(st.sample_count),
+                       "kld_leaf_count": int(st.leaf_count), "parallelism": "particle-shard x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": e.score_kernel_name(), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
+                         "launches_timed": int(score["launches"])},
+            "cpu_baseline": cpu,
+            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+        }
+        if mean_cells is not None:
+            line["roofline"]["mean_cells_per_ray"] = mean_cells
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    e.close()
+
+
+if __name__ == "__main__":
+    main()

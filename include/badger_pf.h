@@ -1,0 +1,257 @@
+/*
+ * badger_pf.h -- C-ABI of libbadger_pf_hip.so, the MI355X (gfx950) engine for the
+ * badger_amcl sensor-update + resample hot path.
+ *
+ * Everything here is plain C: opaque handle, pointers and sizes, int status codes.
+ * No exception, C++ type or torch type crosses this boundary.  One engine is used
+ * by one host thread at a time (the reference's seams are single-caller too:
+ * SURVEY.md section 8(b), "Threading").
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the reference checkout).  INTEGRATION.md shows the C++ binding a maintainer of
+ * the reference would add on top of this header.
+ *
+ * Memory conventions
+ *   "samples" buffers are the reference's PFSample array seen as doubles: AoS
+ *   {x, y, theta, weight}, 32 bytes per particle (include/amcl/pf/particle_filter.h:41-49).
+ *   Host pointers are caller-owned and only read/written during the call.
+ *   Functions whose name contains `_dev` take DEVICE pointers the caller owns
+ *   (e.g. a torch tensor's data_ptr()) and run asynchronously on the engine stream.
+ */
+#ifndef BADGER_PF_H
+#define BADGER_PF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bpf_engine bpf_engine;
+
+/* ---- status codes (the reference has none: it returns 0.0 / false or ROS_ASSERTs;
+ * see SURVEY.md 8(b) "Error conventions") */
+enum
+{
+  BPF_OK = 0,
+  BPF_ERR_INVALID_ARGUMENT = 1,
+  BPF_ERR_NOT_CONFIGURED = 2,     /* map / model / filter missing */
+  BPF_ERR_HIP = 3,                /* a HIP runtime call failed; see bpf_last_error_message */
+  BPF_ERR_UNSUPPORTED = 4,        /* e.g. w_diff > 0 needs the node's random_pose_fn_ callback */
+  BPF_ERR_CDF_MISS = 5,           /* reference ROS_ASSERT(i < sample_count), particle_filter.cpp:399 */
+  BPF_ERR_LUT_LEVELS = 6,         /* distance LUT holds more than 65535 distinct values */
+  BPF_ERR_BEAM_STEP = 7,          /* beam model with range_count < max_beams: the reference never returns */
+  BPF_ERR_CAPACITY = 8
+};
+
+enum
+{
+  BPF_MODEL_BEAM = 0,                       /* PLANAR_MODEL_BEAM */
+  BPF_MODEL_LIKELIHOOD_FIELD = 1,           /* PLANAR_MODEL_LIKELIHOOD_FIELD */
+  BPF_MODEL_LIKELIHOOD_FIELD_PROB = 2,      /* PLANAR_MODEL_LIKELIHOOD_FIELD_PROB */
+  BPF_MODEL_LIKELIHOOD_FIELD_GOMPERTZ = 3   /* PLANAR_MODEL_LIKELIHOOD_FIELD_GOMPERTZ */
+};
+
+enum
+{
+  BPF_RESAMPLE_MULTINOMIAL = 0, /* PF_RESAMPLE_MULTINOMIAL */
+  BPF_RESAMPLE_SYSTEMATIC = 1   /* PF_RESAMPLE_SYSTEMATIC */
+};
+
+enum
+{
+  BPF_CLOUD_MODEL = 0,          /* POINT_CLOUD_MODEL */
+  BPF_CLOUD_MODEL_GOMPERTZ = 1  /* POINT_CLOUD_MODEL_GOMPERTZ */
+};
+
+/* ------------------------------------------------------------------ lifecycle */
+int bpf_create(int device_ordinal, bpf_engine** out);
+void bpf_destroy(bpf_engine* e);
+const char* bpf_error_string(int code);
+const char* bpf_last_error_message(const bpf_engine* e);
+/* Run the engine's work on a caller-provided hipStream_t (NULL restores its own). */
+int bpf_set_stream(bpf_engine* e, void* hip_stream);
+int bpf_synchronize(bpf_engine* e);
+
+/* ------------------------------------------------------------------ 2-D map
+ * OccupancyMap state (include/amcl/map/occupancy_map.h:93-102, map.h:48-53):
+ * cells = cells_.data() (MapCellState is a 32-bit enum: -1 free, 0 unknown, +1
+ * occupied; index i + j*size_x), dist_lut = distances_lut_.data() (may be NULL),
+ * origin = origin_.x/.y (float), resolution_, max_distance_to_object_. */
+int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, int size_x, int size_y,
+                  float origin_x, float origin_y, double resolution, double max_dist);
+/* Device-side replacement for OccupancyMap::updateDistancesLUT (occupancy_map.cpp:138-160):
+ * exact Euclidean distance capped at max_dist, on the reference's (a,b)-integer
+ * lattice.  NOT bit-identical to the reference's approximate brushfire; pass the
+ * host LUT to bpf_map2d_set when parity with it matters. */
+int bpf_map2d_build_distances_lut(bpf_engine* e, double max_dist);
+int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity);
+
+/* ------------------------------------------------------------------ planar scanner
+ * PlanarScanner::{init, setModel*, setMapFactors, setPlanarScannerPose}
+ * (include/amcl/sensors/planar_scanner.h:62-93, planar_scanner.cpp:49-121,535-538). */
+int bpf_planar_init(bpf_engine* e, int max_beams);
+int bpf_planar_set_model_beam(bpf_engine* e, double z_hit, double z_short, double z_max, double z_rand,
+                              double sigma_hit, double lambda_short);
+int bpf_planar_set_model_likelihood_field(bpf_engine* e, double z_hit, double z_rand, double sigma_hit,
+                                          double max_distance_to_object);
+int bpf_planar_set_model_likelihood_field_prob(bpf_engine* e, double z_hit, double z_rand, double sigma_hit,
+                                               double max_distance_to_object, int do_beamskip,
+                                               double beam_skip_distance, double beam_skip_threshold,
+                                               double beam_skip_error_threshold);
+int bpf_planar_set_model_likelihood_field_gompertz(bpf_engine* e, double z_hit, double z_rand, double sigma_hit,
+                                                   double max_distance_to_object, double gompertz_a,
+                                                   double gompertz_b, double gompertz_c, double input_shift,
+                                                   double input_scale, double output_shift);
+int bpf_planar_set_map_factors(bpf_engine* e, double off_map_factor, double non_free_space_factor,
+                               double non_free_space_radius);
+int bpf_planar_set_scanner_pose(bpf_engine* e, const double pose[3]);
+
+/* Seam A, host buffers: PlanarScanner::applyModelToSampleSet (planar_scanner.cpp:141-164).
+ * Multiplies samples[i].weight in place for i < sample_count and returns their sum
+ * (0.0 on failure, like the reference); *status (nullable) receives a BPF_* code.
+ * ranges/angles/range_count/range_max are PlanarData (planar_scanner.h:45-54);
+ * set_converged is PFSampleSet::converged (only the prob model reads it). */
+double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int sample_count, int set_converged,
+                                            const double* ranges, const double* angles, int range_count,
+                                            double range_max, int* status);
+
+/* ------------------------------------------------------------------ particle filter
+ * Device-resident ParticleFilter (include/amcl/pf/particle_filter.h:92-184).  The two
+ * ping-pong sample sets live in HBM as structure-of-arrays. */
+int bpf_pf_create(bpf_engine* e, int min_samples, int max_samples, double alpha_slow, double alpha_fast,
+                  double global_localization_convergence_threshold);  /* ctor, particle_filter.cpp:38-98 */
+int bpf_pf_set_resample_model(bpf_engine* e, int resample_model);             /* :100-103 */
+int bpf_pf_set_population_size_parameters(bpf_engine* e, double pop_err, double pop_z); /* :651-655 */
+int bpf_pf_set_decay_rates(bpf_engine* e, double alpha_slow, double alpha_fast);        /* :657-661 */
+/* The reference draws from the process-global drand48 stream (particle_filter.cpp:309,385,393);
+ * the engine carries that 48-bit state explicitly so host code can hand it over and take it back. */
+int bpf_pf_srand48(bpf_engine* e, long seed);
+int bpf_pf_set_rng_state(bpf_engine* e, uint64_t state48);
+int bpf_pf_get_rng_state(const bpf_engine* e, uint64_t* state48);
+/* Load the current set (what initWithPoseFn/initWithGaussian leave behind, :106-162):
+ * resets w_slow/w_fast and converged.  leaf_count = that set's kd-tree leaf count, or -1
+ * to have it computed from the poses. */
+int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, int leaf_count);
+int bpf_pf_get_samples(bpf_engine* e, double* samples_out, int capacity, int* sample_count_out);
+/* Keep a device-resident copy of the current set (poses, weights, counts) and put it back
+ * later with one device-to-device copy -- stands in for the motion update, which rewrites
+ * every pose of the set each cycle (Odom::updateAction, out of scope here). */
+int bpf_pf_snapshot(bpf_engine* e);
+int bpf_pf_restore(bpf_engine* e);
+/* Overwrite the weights of the current set with one value (bench harness: restores 1/N). */
+int bpf_pf_fill_weights(bpf_engine* e, double weight);
+
+/* Seam A on the resident set: PlanarScanner::updateSensor(pf, data)
+ * = ParticleFilter::updateSensor(applyModelToSampleSet, data)
+ * (planar_scanner.cpp:125-137, particle_filter.cpp:223-267).  Asynchronous. */
+int bpf_pf_update_sensor_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                                double range_max);
+/* Seam B: ParticleFilter::updateResample (particle_filter.cpp:423-471). */
+int bpf_pf_update_resample(bpf_engine* e);
+
+/* Engine options.  BPF_OPT_CDF_SERIAL = 1 builds the resampling CDF with the reference's
+ * serial running sum (one lane, bit-exact, slow) instead of the parallel scan;
+ * BPF_OPT_COUNT_CELLS = 1 makes the beam-model kernel count the cells its rays visit. */
+enum
+{
+  BPF_OPT_CDF_SERIAL = 0,
+  BPF_OPT_COUNT_CELLS = 1
+};
+int bpf_set_option(bpf_engine* e, int option, int value);
+/* cells visited by calcRange walks since the last reset (BPF_OPT_COUNT_CELLS) */
+int bpf_get_cells_walked(bpf_engine* e, unsigned long long* out, int reset);
+
+typedef struct
+{
+  int sample_count;       /* PFSampleSet::sample_count of the current set */
+  int leaf_count;         /* its kd-tree leaf count (PFKDTree::getLeafCount) */
+  int bin_count;          /* distinct occupied histogram bins (kd-tree node count) */
+  int converged;          /* ParticleFilter::isConverged */
+  float percent_converged;
+  double total;           /* last sensor_fn total (particle_filter.cpp:235) */
+  double w_slow, w_fast;
+  double w_diff;          /* of the last updateResample */
+  int last_status;        /* BPF_* of the last update_sensor / update_resample */
+  int resample_windows;   /* candidate-draw windows used by the last multinomial resample */
+  long long evals;        /* particle-beam evaluations of the last sensor update */
+} bpf_pf_state;
+int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out);
+
+/* ------------------------------------------------------------------ 3-D map + point cloud
+ * OctoMap LUT state (include/amcl/map/octomap.h:96-110): pose_indices_, distance_ratios_,
+ * cropped_min_cells_, cropped_max_cells_, resolution_, max_distance_to_object_. */
+int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_indices,
+                  const uint8_t* distance_ratios, size_t n_distance_ratios, const int min_cells[3],
+                  const int max_cells[3], double resolution, double max_dist);
+/* PointCloudScanner::{init, setPointCloudModel, setPointCloudModelGompertz, setMapFactors,
+ * setPointCloudScannerToFootprintTF} (point_cloud_scanner.cpp:48-90). */
+int bpf_cloud_init(bpf_engine* e, int max_beams);
+int bpf_cloud_set_model(bpf_engine* e, double z_hit, double z_rand, double sigma_hit);
+int bpf_cloud_set_model_gompertz(bpf_engine* e, double z_hit, double z_rand, double sigma_hit, double gompertz_a,
+                                 double gompertz_b, double gompertz_c, double input_shift, double input_scale,
+                                 double output_shift);
+int bpf_cloud_set_map_factors(bpf_engine* e, double off_map_factor, double non_free_space_factor,
+                              double non_free_space_radius);
+int bpf_cloud_set_scanner_to_footprint_tf(bpf_engine* e, const double xyz[3], const double quat_xyzw[4]);
+/* PointCloudScanner::applyModelToSampleSet (point_cloud_scanner.cpp:106-129); points are
+ * PointCloudData::points_ as packed float xyz triples in the scanner frame. */
+double bpf_cloud_apply_model_to_sample_set(bpf_engine* e, double* samples, int sample_count, const float* points_xyz,
+                                           int n_points, int* status);
+/* PointCloudScanner::updateSensor(pf, data) on the resident set (:92-102). */
+int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_points);
+
+/* ------------------------------------------------------------------ sharded operation
+ * One engine per GPU holds a contiguous shard of the particle set; the host exchanges
+ * the few scalars / key lists between ranks (RCCL or any other transport) and calls
+ * these stage functions.  All device work is asynchronous on the engine stream. */
+/* score + recalcWeight on the local shard; local total lands in device scalar slot 0 */
+int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                           double range_max);
+/* device address of the engine's scalar block: double[8]; [0] = local weight total */
+int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr);
+/* particle_filter.cpp:237-266 with the GLOBAL total and GLOBAL sample count */
+int bpf_shard_normalize(bpf_engine* e, double global_total, int global_sample_count);
+/* local running sum of weights (c[i+1] - c[0]); the host adds the lower ranks' sums */
+int bpf_shard_build_cdf(bpf_engine* e, double* local_sum_out);
+/* For global draws m in [m0, m1) of the multinomial resampler whose r falls in
+ * [cdf_offset, cdf_offset + local_sum): source pose and histogram key.  Results are
+ * compacted in draw order: draw_index[], pose xyz triples, key triples. */
+int bpf_shard_draw_select(bpf_engine* e, uint64_t rng_state48, int m0, int m1, double cdf_offset, int is_last_shard,
+                          int* draw_index_out, double* poses_out, int* keys_out, int capacity, int* count_out,
+                          int* miss_out);
+/* Host-side exact KLD stop rule: replay ordered histogram keys through the fork's kd-tree
+ * (pf_kdtree.cpp:97-150) and apply resampleLimit after each (particle_filter.cpp:416).
+ * State persists in the engine between calls so windows can be fed one after another. */
+int bpf_kld_reset(bpf_engine* e);
+int bpf_kld_feed(bpf_engine* e, const int* keys, int n_keys, int first_draw_index, int* stop_count_out);
+int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out);
+
+/* ------------------------------------------------------------------ measurement */
+enum
+{
+  BPF_K_SCORE = 0,     /* sensor scoring kernel (the dominant one) */
+  BPF_K_REDUCE = 1,
+  BPF_K_NORMALIZE = 2,
+  BPF_K_CDF = 3,
+  BPF_K_DRAW = 4,
+  BPF_K_FINALIZE = 5,
+  BPF_K_COUNT = 8
+};
+typedef struct
+{
+  double ms[BPF_K_COUNT];          /* accumulated HIP-event time per kernel class */
+  long long launches[BPF_K_COUNT];
+} bpf_profile;
+/* When on, every launch of the dominant kernel is bracketed by hipEvents on the engine stream. */
+int bpf_profile_enable(bpf_engine* e, int on);
+int bpf_profile_reset(bpf_engine* e);
+int bpf_profile_get(bpf_engine* e, bpf_profile* out);
+/* Name of the scoring kernel as rocprofv3 prints it, for matching profiles/ summaries. */
+const char* bpf_score_kernel_name(const bpf_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BADGER_PF_H */
