@@ -10,7 +10,10 @@ namespace bpf
 //  * lut_tiles: the distance LUT re-encoded as 16-bit level indices in 8x8-cell tiles
 //    (one tile = 128 B = one cache line), so that beam end points that are close in
 //    EITHER axis share lines.  levels[idx] is the float distance of the reference's
-//    distances_lut_ (include/amcl/map/occupancy_map.h:99).
+//    distances_lut_ (include/amcl/map/occupancy_map.h:99).  The tiled image carries a
+//    border of one tile (8 cells) on every side filled with the off-map level K: an end
+//    point is clamped into [7, size+8] per axis and looked up without any bounds test.
+//    Element offset of padded cell (u, v):  (v&~7)*(8*ltx-8) + 8*v + (u&~7)*7 + u.
 //  * notfree_tiles: one bit per cell (1 = not CELL_FREE), 8x8 cells per 64-bit word;
 //    bits of cells beyond the map edge inside a partial tile are 1.
 //  * cells8: the tri-state grid narrowed to int8, row-major i + j*size_x.
@@ -21,8 +24,9 @@ struct MapDev
   const int8_t* cells8;
   const float* levels;
   int size_x, size_y;
-  int tiles_x, tiles_y;
-  int half_x, half_y;  // size/2, the centre offset of convertWorldToMap
+  int tiles_x, tiles_y;   // tiles of the un-padded grid (notfree_tiles)
+  int ltx, lty;           // tiles per row / column of the padded LUT image (tiles + 2)
+  int half_x, half_y;     // size/2, the centre offset of convertWorldToMap
   int n_levels;        // K; index K is reserved for "off map"
   double origin_x, origin_y;  // float origin promoted to double (occupancy_map.cpp:96-97)
   double resolution;
@@ -56,11 +60,10 @@ struct FieldScoreArgs
   double off_map_factor, non_free_factor, non_free_radius;
   int model;
   GompertzDev g;
-  // prob model
-  const uint8_t* beam_mask;  // per valid-beam slot: 1 = integrate (nullable = all)
-  int* obs_count;            // per valid-beam slot agreement counts (nullable)
+  int n_valid;               // beams that count towards the Gompertz mean
+  // prob model, counting pass
+  int* obs_count;            // per staged beam: particles whose end point is near an obstacle
   int skip_level;            // levels below this index are "z < beam_skip_distance"
-  int count_only;            // 1: only fill obs_count, leave weights alone
 };
 
 // drand48 jump-ahead tables: A[j] = a^(2^j), C[j] = c*(a^(2^j)-1)/(a-1)  (mod 2^48)

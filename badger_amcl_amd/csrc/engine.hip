@@ -147,7 +147,6 @@ struct bpf_engine
   ScanSlot ring[kRing];
   int ring_next = 0;
   DevBuf<int> d_obs_count;
-  DevBuf<uint8_t> d_beam_mask;
   DevBuf<unsigned long long> d_cells_walked;
 
   // ---- particle filter
@@ -173,6 +172,7 @@ struct bpf_engine
   bool cdf_serial = false;
   bool count_cells = false;
   KdHistogram hist;
+  SeenKeys seen;
   DevBuf<double> d_cdf, d_partials, d_targets;
   DevBuf<FilterScalars> d_scalars;
   DevBuf<int> d_keys, d_src_index, d_flags;  // d_flags[0] miss, [1] converged count
@@ -298,8 +298,10 @@ int encode_lut(bpf_engine* e, const float* lut)
     std::memcpy(&bits, &levels[k], 4);
     seen[bits] = (int)k;
   }
-  const int tx = e->map.tiles_x, ty = e->map.tiles_y;
-  std::vector<uint16_t> tiles((size_t)tx * ty * 64, 0);
+  // padded image: one tile of border all round, filled with the off-map level K
+  const int tx = e->map.ltx, ty = e->map.lty;
+  const uint16_t off_map_level = (uint16_t)levels.size();
+  std::vector<uint16_t> tiles((size_t)tx * ty * 64, off_map_level);
   for (int j = 0; j < sy; ++j)
   {
     uint32_t prev_bits = 0;
@@ -313,7 +315,8 @@ int encode_lut(bpf_engine* e, const float* lut)
         prev_idx = seen[bits];
         prev_bits = bits;
       }
-      tiles[((size_t)(j >> 3) * tx + (i >> 3)) * 64 + ((j & 7) << 3) + (i & 7)] = (uint16_t)prev_idx;
+      const int u = i + 8, v = j + 8;
+      tiles[((size_t)(v >> 3) * tx + (u >> 3)) * 64 + ((v & 7) << 3) + (u & 7)] = (uint16_t)prev_idx;
     }
   }
   HIPCHK(e, e->d_lut_tiles.reserve(tiles.size()));
@@ -381,9 +384,10 @@ int release_slot(bpf_engine* e, ScanSlot* s)
 
 struct FieldScan
 {
-  int n_valid = 0;
+  int n_valid = 0;             // beams that pass the range_max / NaN tests
+  int n_staged = 0;            // of those, the ones uploaded (all, or the kept ones of beam skipping)
   int n_slots = 0;             // beam_ind range of the prob model
-  std::vector<int> slot_of;    // valid beam -> beam_ind
+  std::vector<int> slot_of;    // staged beam -> beam_ind
   size_t beams_off = 0, table_off = 0, bytes = 0;
   int table_len = 0;
 };
@@ -391,7 +395,7 @@ struct FieldScan
 // Host half of calcLikelihoodFieldModel{,Prob,Gompertz}: beam decimation and validity
 // (planar_scanner.cpp:265-282, :339-343,410-425, :578-597) and the per-level term table.
 int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, int rc, double range_max,
-                     ScanSlot** slot_out, FieldScan* fs)
+                     ScanSlot** slot_out, FieldScan* fs, const std::vector<uint8_t>* keep_slot = nullptr)
 {
   const PlanarModel& pm = e->pm;
   int step;
@@ -406,6 +410,7 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
   std::vector<double2> beams;
   beams.reserve(rc / step + 1);
   fs->slot_of.clear();
+  fs->n_valid = 0;
   int slot = 0;
   const double res = e->map.resolution;
   for (int i = 0; i < rc; i += step, ++slot)
@@ -415,18 +420,28 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
       continue;
     if (r != r)
       continue;
+    ++fs->n_valid;
+    if (keep_slot && !(slot < (int)keep_slot->size() && (*keep_slot)[slot]))
+      continue;
     double2 b;
     b.x = (r * std::cos(angles[i])) / res;
     b.y = (r * std::sin(angles[i])) / res;
+    // a non-finite or absurdly long beam ends off the map in the reference ((int) of a NaN or
+    // huge double is INT_MIN on x86); (1e18, 0) rotates to an off-map end point for every pose
+    if (!(std::fabs(b.x) < 1e15 && std::fabs(b.y) < 1e15))
+    {
+      b.x = 1e18;
+      b.y = 0.0;
+    }
     beams.push_back(b);
     fs->slot_of.push_back(slot);
   }
   fs->n_slots = slot;
-  fs->n_valid = (int)beams.size();
-  if (fs->n_valid > kMaxBeams)
+  fs->n_staged = (int)beams.size();
+  if (fs->n_staged > kMaxBeams)
     return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
   fs->beams_off = 0;
-  fs->table_off = ((size_t)fs->n_valid * sizeof(double2) + 255) & ~(size_t)255;
+  fs->table_off = ((size_t)fs->n_staged * sizeof(double2) + 255) & ~(size_t)255;
   fs->bytes = fs->table_off + (size_t)fs->table_len * sizeof(double);
   ScanSlot* s;
   int rcode = acquire_slot(e, fs->bytes, &s);
@@ -471,14 +486,14 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
   return BPF_OK;
 }
 
-int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldScan& fs, const uint8_t* mask,
-                 int* obs_count, int skip_level, int count_only)
+int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldScan& fs, int* obs_count,
+                 int skip_level)
 {
   FieldScoreArgs A{};
   A.p = p;
   A.n = n;
   A.beams = reinterpret_cast<const double2*>(s->dev.p + fs.beams_off);
-  A.n_beams = fs.n_valid;
+  A.n_beams = fs.n_staged;
   A.table = reinterpret_cast<const double*>(s->dev.p + fs.table_off);
   A.table_len = fs.table_len;
   A.map = e->map;
@@ -490,21 +505,23 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   A.non_free_radius = e->pm.non_free_radius;
   A.model = e->pm.model;
   A.g = e->pm.g;
-  A.beam_mask = mask;
+  A.n_valid = fs.n_valid;
   A.obs_count = obs_count;
   A.skip_level = skip_level;
-  A.count_only = count_only;
-  const bool table_lds = fs.table_len <= kTableLdsMax;
-  const size_t lds = (size_t)fs.n_valid * sizeof(double2) + (table_lds ? (size_t)fs.table_len * sizeof(double) : 0);
+  const bool count_only = obs_count != nullptr;
+  const bool table_lds = !count_only && fs.table_len <= kTableLdsMax;
+  const size_t lds = (size_t)fs.n_staged * sizeof(double2) + (table_lds ? (size_t)fs.table_len * sizeof(double) : 0);
   const int n_groups = (n + 15) / 16;
   int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1024));
   per_cu = std::max(per_cu, 1);
   const int grid = std::max(1, std::min(blocks_for(n_groups, 4), e->n_cu * per_cu));
   ProfScope ps(e, BPF_K_SCORE);
-  if (table_lds)
-    hipLaunchKernelGGL(k_score_field<true>, dim3(grid), dim3(256), lds, e->stream, A);
+  if (count_only)
+    hipLaunchKernelGGL((k_score_field<true, false>), dim3(grid), dim3(256), lds, e->stream, A);
+  else if (table_lds)
+    hipLaunchKernelGGL((k_score_field<false, true>), dim3(grid), dim3(256), lds, e->stream, A);
   else
-    hipLaunchKernelGGL(k_score_field<false>, dim3(grid), dim3(256), lds, e->stream, A);
+    hipLaunchKernelGGL((k_score_field<false, false>), dim3(grid), dim3(256), lds, e->stream, A);
   HIPCHK(e, hipGetLastError());
   return BPF_OK;
 }
@@ -627,7 +644,7 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
   const bool beamskip = pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && pm.do_beamskip && set_converged;
   if (!beamskip)
   {
-    rcode = launch_field(e, p, n, s, fs, nullptr, nullptr, 0, 0);
+    rcode = launch_field(e, p, n, s, fs, nullptr, 0);
     if (rcode != BPF_OK)
       return rcode;
     return release_slot(e, s);
@@ -637,22 +654,24 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
   // whose end point lies within beam_skip_distance of an obstacle; the host forms the mask;
   // pass 2 integrates the kept beams.  (The reference stores every pz in an N x max_beams
   // scratch matrix between the passes; re-evaluating is cheaper than 8 B x N x beams of HBM.)
-  const int nv = std::max(fs.n_valid, 1);
+  const int nv = std::max(fs.n_staged, 1);
   HIPCHK(e, e->d_obs_count.reserve((size_t)nv));
-  HIPCHK(e, e->d_beam_mask.reserve((size_t)nv));
   HIPCHK(e, hipMemsetAsync(e->d_obs_count.p, 0, (size_t)nv * sizeof(int), e->stream));
   int skip_level = 0;  // levels are ascending: z < d  <=>  level index < first level >= d
   while (skip_level < e->map.n_levels && (double)e->h_levels[skip_level] < pm.beam_skip_distance)
     ++skip_level;
-  rcode = launch_field(e, p, n, s, fs, nullptr, e->d_obs_count.p, skip_level, 1);
+  rcode = launch_field(e, p, n, s, fs, e->d_obs_count.p, skip_level);
+  if (rcode != BPF_OK)
+    return rcode;
+  rcode = release_slot(e, s);
   if (rcode != BPF_OK)
     return rcode;
   std::vector<int> counts((size_t)nv, 0);
-  HIPCHK(e, hipMemcpyAsync(counts.data(), e->d_obs_count.p, (size_t)fs.n_valid * sizeof(int), hipMemcpyDeviceToHost,
+  HIPCHK(e, hipMemcpyAsync(counts.data(), e->d_obs_count.p, (size_t)fs.n_staged * sizeof(int), hipMemcpyDeviceToHost,
                            e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   std::vector<int> obs_count((size_t)pm.max_beams, 0);
-  for (int v = 0; v < fs.n_valid; ++v)
+  for (int v = 0; v < fs.n_staged; ++v)
     if (fs.slot_of[v] < pm.max_beams)
       obs_count[fs.slot_of[v]] = counts[v];
   std::vector<uint8_t> mask_slot((size_t)pm.max_beams, 0);
@@ -668,7 +687,7 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
   // A kept slot that was never written holds 0.0 in the reference's scratch matrix, and
   // log(0) = -inf zeroes every weight (planar_scanner.cpp:519-527).
   std::vector<uint8_t> visited((size_t)pm.max_beams, 0);
-  for (int v = 0; v < fs.n_valid; ++v)
+  for (int v = 0; v < fs.n_staged; ++v)
     if (fs.slot_of[v] < pm.max_beams)
       visited[fs.slot_of[v]] = 1;
   bool poisoned = false;
@@ -680,17 +699,21 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     hipLaunchKernelGGL(k_fill, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, p.w, 0.0, n);
     HIPCHK(e, hipGetLastError());
     *forced_zero = true;
-    return release_slot(e, s);
+    return BPF_OK;
   }
-  std::vector<uint8_t> mask_valid((size_t)nv, 0);
-  for (int v = 0; v < fs.n_valid; ++v)
-    mask_valid[v] = error ? 1 : mask_slot[fs.slot_of[v]];
-  HIPCHK(e, hipMemcpyAsync(e->d_beam_mask.p, mask_valid.data(), (size_t)fs.n_valid, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));  // mask_valid is pageable and about to go out of scope
-  rcode = launch_field(e, p, n, s, fs, e->d_beam_mask.p, nullptr, 0, 0);
+  // pass 2: stage only the kept beams (all of them when the error switch tripped) and score
+  std::vector<uint8_t> keep((size_t)std::max(fs.n_slots, pm.max_beams), 0);
+  for (size_t b = 0; b < keep.size(); ++b)
+    keep[b] = error ? 1 : ((int)b < pm.max_beams ? mask_slot[b] : 0);
+  ScanSlot* s2 = nullptr;
+  FieldScan fs2;
+  rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s2, &fs2, &keep);
   if (rcode != BPF_OK)
     return rcode;
-  return release_slot(e, s);
+  rcode = launch_field(e, p, n, s2, fs2, nullptr, 0);
+  if (rcode != BPF_OK)
+    return rcode;
+  return release_slot(e, s2);
 }
 
 int fetch_scalars(bpf_engine* e)
@@ -760,6 +783,7 @@ int resample_multinomial(bpf_engine* e)
   HIPCHK(e, e->h_keys.reserve((size_t)maxs * 3));
   HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
   e->hist.clear();
+  e->seen.reset((size_t)std::min(maxs, 1 << 20));
   int m0 = 0, stop = -1;
   int window = std::max(1024, std::min(e->window_hint, maxs));
   e->resample_windows = 0;
@@ -793,12 +817,15 @@ int resample_multinomial(bpf_engine* e)
     for (int m = m0; m < m1; ++m)
     {
       const int* k = &keys[3 * (m - m0)];
-      e->hist.insert(k[0], k[1], k[2]);
-      const int lc = e->hist.leaf_count();
-      if (lc != cached_leaf)
+      if (e->seen.first_time(k[0], k[1], k[2]))
       {
-        cached_leaf = lc;
-        cached_limit = resample_limit(lc, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+        e->hist.insert(k[0], k[1], k[2]);
+        const int lc = e->hist.leaf_count();
+        if (lc != cached_leaf)
+        {
+          cached_leaf = lc;
+          cached_limit = resample_limit(lc, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+        }
       }
       if (m + 1 > cached_limit)  // particle_filter.cpp:416
       {
@@ -850,8 +877,10 @@ int resample_systematic(bpf_engine* e)
   HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)count * 3 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->hist.clear();
+  e->seen.reset((size_t)std::min(count, 1 << 20));
   for (int m = 0; m < count; ++m)
-    e->hist.insert(e->h_keys.p[3 * m], e->h_keys.p[3 * m + 1], e->h_keys.p[3 * m + 2]);
+    if (e->seen.first_time(e->h_keys.p[3 * m], e->h_keys.p[3 * m + 1], e->h_keys.p[3 * m + 2]))
+      e->hist.insert(e->h_keys.p[3 * m], e->h_keys.p[3 * m + 1], e->h_keys.p[3 * m + 2]);
   e->resample_windows = 1;
   e->sample_count = count;
   return BPF_OK;
@@ -920,7 +949,7 @@ void bpf_destroy(bpf_engine* e)
   for (auto ev : e->ev_stop)
     (void)hipEventDestroy(ev);
   e->d_lut_tiles.release(); e->d_notfree.release(); e->d_cells8.release(); e->d_levels.release();
-  e->d_lut_f32.release(); e->d_edt_tmp.release(); e->d_obs_count.release(); e->d_beam_mask.release();
+  e->d_lut_f32.release(); e->d_edt_tmp.release(); e->d_obs_count.release();
   e->d_cells_walked.release();
   e->sets[0].release(); e->sets[1].release(); e->scratch.release(); e->snap.release();
   e->d_cdf.release(); e->d_partials.release(); e->d_targets.release(); e->d_scalars.release();
@@ -984,6 +1013,10 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
   M.size_y = size_y;
   M.tiles_x = (size_x + 7) / 8;
   M.tiles_y = (size_y + 7) / 8;
+  M.ltx = (size_x + 8 + 8 + 7) / 8;  // cells -8 .. size+8 inclusive
+  M.lty = (size_y + 8 + 8 + 7) / 8;
+  if ((size_t)M.ltx * 16 >= (1u << 24) || (size_t)M.ltx * M.lty * 128 >= (1ull << 32))
+    return e->fail(BPF_ERR_CAPACITY, "map too large for the 32-bit tiled LUT addressing");
   M.half_x = size_x / 2;
   M.half_y = size_y / 2;
   M.origin_x = (double)origin_x;

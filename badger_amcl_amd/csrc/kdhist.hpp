@@ -7,6 +7,7 @@
 // after every draw (particle_filter.cpp:416).  That stop rule is inherently sequential, so
 // it stays on the host: the GPU produces the ordered key stream, this class replays it.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -136,6 +137,62 @@ private:
   std::vector<int> lo_, hi_;
   std::vector<int> label_;
   int leaves_ = 0;
+};
+
+// Generation-stamped open-addressing set of bin keys: lets the replay skip the tree walk for a
+// key it has already inserted (a repeated key only adds to the bin's weight, pf_kdtree.cpp:107-110,
+// and changes neither the tree shape nor the leaf count).
+class SeenKeys
+{
+public:
+  void reset(size_t expected)
+  {
+    size_t want = 1024;
+    while (want < expected * 4)
+      want <<= 1;
+    if (want != keys_.size())
+    {
+      keys_.assign(want, 0);
+      gen_.assign(want, 0);
+      cur_ = 0;
+    }
+    if (++cur_ == 0)
+    {
+      std::fill(gen_.begin(), gen_.end(), 0u);
+      cur_ = 1;
+    }
+    used_ = 0;
+  }
+
+  // true when the key was not in the set (and is now); keys outside +-2^20 bins are never cached
+  bool first_time(int x, int y, int t)
+  {
+    const int lim = 1 << 20;
+    if (x < -lim || x >= lim || y < -lim || y >= lim || t < -lim || t >= lim || used_ * 2 > keys_.size())
+      return true;
+    const uint64_t k = ((uint64_t)(x + lim) << 42) | ((uint64_t)(y + lim) << 21) | (uint64_t)(t + lim);
+    uint64_t h = k * 0x9E3779B97F4A7C15ull;
+    size_t i = (size_t)(h >> 20) & (keys_.size() - 1);
+    for (;;)
+    {
+      if (gen_[i] != cur_)
+      {
+        gen_[i] = cur_;
+        keys_[i] = k;
+        ++used_;
+        return true;
+      }
+      if (keys_[i] == k)
+        return false;
+      i = (i + 1) & (keys_.size() - 1);
+    }
+  }
+
+private:
+  std::vector<uint64_t> keys_;
+  std::vector<uint32_t> gen_;
+  uint32_t cur_ = 0;
+  size_t used_ = 0;
 };
 
 // ParticleFilter::resampleLimit (particle_filter.cpp:475-502)

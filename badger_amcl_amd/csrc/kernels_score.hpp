@@ -45,6 +45,29 @@ __device__ __forceinline__ int world_to_cell(double v, double origin, double res
   return (f == f) ? (int)f + half : -1;
 }
 
+constexpr int kLutPad = 8;  // border cells of the padded LUT image
+
+// clamp(x, lo, hi); the bound is asserted so the compiler may fold max+min into v_med3_i32
+__device__ __forceinline__ int clamp_i32(int x, int lo, int hi)
+{
+  __builtin_assume(hi >= lo);
+  return min(max(x, lo), hi);
+}
+
+// byte offset of padded cell (u, v) in lut_tiles (see MapDev)
+__device__ __forceinline__ unsigned lut_byte_offset(const MapDev& m, int u, int v)
+{
+  const unsigned a = (unsigned)u & ~7u, b = (unsigned)v & ~7u;
+  const unsigned t = __umul24(a, 14u) + ((unsigned)u << 1);
+  const unsigned t2 = __umul24(b, (unsigned)(16 * m.ltx - 16)) + t;
+  return ((unsigned)v << 4) + t2;
+}
+
+__device__ __forceinline__ unsigned lut_level(const MapDev& m, int u, int v)
+{
+  return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(m.lut_tiles) + lut_byte_offset(m, u, v));
+}
+
 // PlanarScanner::recalcWeight for one particle (planar_scanner.cpp:642-682)
 __device__ __forceinline__ double recalc_factor(const MapDev& m, double px, double py, double off_map_factor,
                                                 double non_free_factor, double non_free_radius)
@@ -55,8 +78,7 @@ __device__ __forceinline__ double recalc_factor(const MapDev& m, double px, doub
     return off_map_factor;
   if (m.cells8[ci + (size_t)cj * m.size_x] != -1)
     return non_free_factor;
-  const unsigned tile = (unsigned)(cj >> 3) * m.tiles_x + (ci >> 3);
-  const unsigned idx = m.lut_tiles[(size_t)tile * 64 + ((cj & 7) << 3) + (ci & 7)];
+  const unsigned idx = lut_level(m, ci + kLutPad, cj + kLutPad);
   const double d = (double)m.levels[idx];
   if (d < non_free_radius)
   {
@@ -100,7 +122,25 @@ __device__ __forceinline__ ScannerPose scanner_pose(double px, double py, double
 //     table indexed by the 16-bit level id of the cell, built on the host with the same
 //     libm expression as the reference (no transcendental in the loop, identical terms).
 // ---------------------------------------------------------------------------------------
-template <bool TABLE_IN_LDS>
+// One likelihood-field evaluation up to the cell.  (qx, qy) already hold
+// (scanner - origin)/res + 0.5 + size/2 + kLutPad, so the padded cell index is the truncation of
+// the end point (truncation == floor for every end point on the map or in the border, all of
+// which are positive); anything else is clamped into the border, which stores the off-map level.
+__device__ __forceinline__ unsigned field_cell(const MapDev& M, double c, double s, double qx, double qy,
+                                               const double2 B)
+{
+  const double vx = fma(c, B.x, fma(-s, B.y, qx));
+  const double vy = fma(s, B.x, fma(c, B.y, qy));
+  // v_cvt_i32_f64 saturates; NaNs were removed when the particle and the beam table were prepared
+  const int u = clamp_i32((int)vx, kLutPad - 1, M.size_x + kLutPad);
+  const int v = clamp_i32((int)vy, kLutPad - 1, M.size_y + kLutPad);
+  return lut_byte_offset(M, u, v);
+}
+
+constexpr int kFieldUnroll = 8;
+
+// COUNT_ONLY: pass 1 of the prob model's beam skipping -- only the per-beam agreement counts.
+template <bool COUNT_ONLY, bool TABLE_IN_LDS>
 __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
 {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -110,7 +150,7 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
   const int tid = threadIdx.x;
   for (int i = tid; i < A.n_beams; i += 256)
     s_beams[i] = A.beams[i];
-  if (TABLE_IN_LDS)
+  if (TABLE_IN_LDS && !COUNT_ONLY)
     for (int i = tid; i < A.table_len; i += 256)
       s_table[i] = A.table[i];
   __syncthreads();
@@ -120,8 +160,9 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
   const int wave = tid >> 6;
   const int n_groups = (A.n + 15) >> 4;
   const MapDev& M = A.map;
-  const unsigned off_map_level = (unsigned)M.n_levels;
   const double* table = TABLE_IN_LDS ? s_table : A.table;
+  const char* __restrict__ tiles = reinterpret_cast<const char*>(M.lut_tiles);
+  const int n_beams = A.n_beams;
 
   for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4)
   {
@@ -129,10 +170,20 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
     const int cnt = min(16, A.n - base);
     const int pi = base + min(sub, cnt - 1);
     const double px = A.p.x[pi], py = A.p.y[pi], pth = A.p.th[pi];
-    const ScannerPose sp = scanner_pose(px, py, pth, A.sp_x, A.sp_y, A.sp_th);
-    // end point in cell units: floor(Px + c*Bx - s*By) + half  (0.5 folded into Px)
-    const double Px = (sp.x - M.origin_x) / M.resolution + 0.5;
-    const double Py = (sp.y - M.origin_y) / M.resolution + 0.5;
+    ScannerPose sp = scanner_pose(px, py, pth, A.sp_x, A.sp_y, A.sp_th);
+    // end point in padded cell units: trunc(Px + c*Bx - s*By), with 0.5, size/2 and the border
+    // folded into Px
+    double Px = ((sp.x - M.origin_x) / M.resolution + 0.5) + (double)(M.half_x + kLutPad);
+    double Py = ((sp.y - M.origin_y) / M.resolution + 0.5) + (double)(M.half_y + kLutPad);
+    // A pose with a NaN / infinite component puts every end point off the map in the reference
+    // ((int)NaN is INT_MIN on x86); do the same here once per particle instead of per beam.
+    if (!(fabs(sp.c) <= 1.0 && fabs(sp.s) <= 1.0 && fabs(Px) < 1e15 && fabs(Py) < 1e15))
+    {
+      sp.c = 0.0;
+      sp.s = 0.0;
+      Px = -4e18;
+      Py = -4e18;
+    }
 
     double mine = 0.0;
     for (int k = 0; k < cnt; ++k)
@@ -140,41 +191,56 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
       const double c = lane_bcast(sp.c, k), s = lane_bcast(sp.s, k);
       const double qx = lane_bcast(Px, k), qy = lane_bcast(Py, k);
       double acc = 0.0;
-      for (int b = lane; b < A.n_beams; b += 64)
+      int b = lane;
+      if (!COUNT_ONLY)
       {
-        const double2 B = s_beams[b];
-        const double vx = fma(c, B.x, fma(-s, B.y, qx));
-        const double vy = fma(s, B.x, fma(c, B.y, qy));
-        const double fx = floor(vx), fy = floor(vy);
-        const int ix = (fx == fx) ? (int)fx + M.half_x : -1;
-        const int iy = (fy == fy) ? (int)fy + M.half_y : -1;
-        const bool on_map = (unsigned)ix < (unsigned)M.size_x && (unsigned)iy < (unsigned)M.size_y;
-        unsigned level = off_map_level;
-        if (on_map)
+        // full batches: kFieldUnroll independent gathers in flight per lane
+        for (; b + 64 * (kFieldUnroll - 1) < n_beams; b += 64 * kFieldUnroll)
         {
-          const unsigned tile = (unsigned)(iy >> 3) * M.tiles_x + (ix >> 3);
-          level = M.lut_tiles[(size_t)tile * 64 + ((iy & 7) << 3) + (ix & 7)];
+          unsigned off[kFieldUnroll];
+          unsigned lv[kFieldUnroll];
+#pragma unroll
+          for (int u = 0; u < kFieldUnroll; ++u)
+            off[u] = field_cell(M, c, s, qx, qy, s_beams[b + 64 * u]);
+#pragma unroll
+          for (int u = 0; u < kFieldUnroll; ++u)
+            lv[u] = *reinterpret_cast<const uint16_t*>(tiles + off[u]);
+#pragma unroll
+          for (int u = 0; u < kFieldUnroll; ++u)
+            acc += table[lv[u]];
         }
-        if (A.obs_count != nullptr && on_map && (int)level < A.skip_level)
-          atomicAdd(&A.obs_count[b], 1);
-        if (A.beam_mask == nullptr || A.beam_mask[b])
-          acc += table[level];
       }
-      const double tot = wave_sum(acc);
-      if (sub == k)
-        mine = tot;
+      for (; b < n_beams; b += 64)
+      {
+        const unsigned off = field_cell(M, c, s, qx, qy, s_beams[b]);
+        const unsigned lv = *reinterpret_cast<const uint16_t*>(tiles + off);
+        if (COUNT_ONLY)
+        {
+          // skip_level <= K, so the border's off-map level never counts (planar_scanner.cpp:441-451)
+          if ((int)lv < A.skip_level)
+            atomicAdd(&A.obs_count[b], 1);
+        }
+        else
+          acc += table[lv];
+      }
+      if (!COUNT_ONLY)
+      {
+        const double tot = wave_sum(acc);
+        if (sub == k)
+          mine = tot;
+      }
     }
 
-    if (lane < cnt && !A.count_only)
+    if (!COUNT_ONLY && lane < cnt)
     {
       double p;
       if (A.model == 1)  // likelihood field: p = 1 + sum pz^3
         p = 1.0 + mine;
       else if (A.model == 3)  // Gompertz of the mean pz (planar_scanner.cpp:540-550,624-633)
       {
-        if (A.n_beams > 0)
+        if (A.n_valid > 0)
         {
-          double v = mine / A.n_beams;
+          double v = mine / A.n_valid;
           v = v * A.g.input_scale + A.g.input_shift;
           v = A.g.a * exp(-1.0 * A.g.b * exp(-1.0 * A.g.c * v));
           p = v + A.g.output_shift;
