@@ -73,12 +73,15 @@ SIGNATURES = {
     "bpf_pf_update_sensor_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "bpf_shard_score_planar": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double]),
     "bpf_shard_scalars_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
-    "bpf_shard_normalize": (C.c_int, [_vp, C.c_double, C.c_int]),
-    "bpf_shard_build_cdf": (C.c_int, [_vp, _dp]),
-    "bpf_shard_draw_select": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, _ip, _dp, _ip,
-                                        C.c_int, _ip, _ip]),
+    "bpf_shard_normalize_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "bpf_shard_build_cdf": (C.c_int, [_vp]),
+    "bpf_shard_draw_window_dev": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int,
+                                            _vp]),
+    "bpf_shard_adopt_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bpf_shard_converged_dev": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "bpf_drand48_skip": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "bpf_kld_reset": (C.c_int, [_vp]),
-    "bpf_kld_feed": (C.c_int, [_vp, _ip, C.c_int, C.c_int, _ip]),
+    "bpf_kld_feed": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "bpf_kld_leaf_count": (C.c_int, [_vp, _ip, _ip]),
     "bpf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "bpf_profile_reset": (C.c_int, [_vp]),

@@ -164,6 +164,7 @@ struct bpf_engine
   int converged = 0;
   float percent_converged = 0;
   bool converged_pending = false;
+  int conv_n = 0;
   double w_diff_last = 0;
   int last_status = BPF_OK;
   int resample_windows = 0;
@@ -724,7 +725,7 @@ int fetch_scalars(bpf_engine* e)
   if (e->converged_pending)
   {
     // particle_filter.cpp:206-219, float arithmetic for the percentage
-    const double pct = (float)e->h_flags.p[1] / (float)e->sample_count * 100;
+    const double pct = (float)e->h_flags.p[1] / (float)e->conv_n * 100;
     e->percent_converged = (float)pct;
     e->converged = pct >= e->conv_threshold;
     e->converged_pending = false;
@@ -769,6 +770,7 @@ int launch_converged(bpf_engine* e)
                      e->dist_threshold, e->d_flags.p + 1);
   HIPCHK(e, hipGetLastError());
   e->converged_pending = true;
+  e->conv_n = n;
   return BPF_OK;
 }
 
@@ -1594,102 +1596,118 @@ int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr)
   return BPF_OK;
 }
 
-int bpf_shard_normalize(bpf_engine* e, double global_total, int global_sample_count)
+int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, int global_sample_count)
 {
-  if (!e || !e->have_pf)
+  if (!e || !e->have_pf || !totals_dev || world <= 0)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
   const int n = e->sample_count;
-  hipLaunchKernelGGL(k_normalize, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.w.p, n, e->d_scalars.p, 1,
-                     global_total, global_sample_count);
+  ProfScope ps(e, BPF_K_NORMALIZE);
+  hipLaunchKernelGGL(k_normalize_gathered, dim3(std::max(1, blocks_for(n, 256))), dim3(256), 0, e->stream, s.w.p, n,
+                     static_cast<const double*>(totals_dev), world, global_sample_count, e->d_scalars.p,
+                     e->alpha_slow, e->alpha_fast);
   HIPCHK(e, hipGetLastError());
   return BPF_OK;
 }
 
-int bpf_shard_build_cdf(bpf_engine* e, double* local_sum_out)
+int bpf_shard_build_cdf(bpf_engine* e)
 {
-  if (!e || !e->have_pf || !local_sum_out)
+  if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
   int rc = build_cdf(e, e->sets[e->cur].w.p, e->sample_count);
   if (rc != BPF_OK)
     return rc;
-  HIPCHK(e, hipMemcpyAsync(local_sum_out, e->d_cdf.p + e->sample_count, sizeof(double), hipMemcpyDeviceToHost,
-                           e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipMemcpyAsync(&e->d_scalars.p->v[7], e->d_cdf.p + e->sample_count, sizeof(double),
+                           hipMemcpyDeviceToDevice, e->stream));
   return BPF_OK;
 }
 
-int bpf_shard_draw_select(bpf_engine* e, uint64_t rng_state48, int m0, int m1, double cdf_offset, int is_last_shard,
-                          int* draw_index_out, double* poses_out, int* keys_out, int capacity, int* count_out,
-                          int* miss_out)
+int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev, int rank,
+                              int world, void* window_dev, int stride, void* flags_dev)
 {
-  if (!e || !e->have_pf || !draw_index_out || !poses_out || !keys_out || !count_out || m1 < m0)
-    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e || !e->have_pf || !sums_dev || !window_dev || !flags_dev || m1 <= m0 || stride < m1 - m0 || rank < 0 ||
+      rank >= world)
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad draw window arguments") : BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
-  const int w = m1 - m0;
-  SampleSet& a = e->sets[e->cur];
-  HIPCHK(e, e->d_keys.reserve((size_t)std::max(w, 1) * 3));
-  HIPCHK(e, e->d_src_index.reserve((size_t)std::max(w, 1)));
-  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
-  DrawArgs A{};
-  A.src = a.dev();
+  WindowArgs A{};
+  A.src = e->sets[e->cur].dev();
   A.n_src = e->sample_count;
   A.cdf = e->d_cdf.p;
-  A.dst = ParticlesDev{ nullptr, nullptr, nullptr, nullptr };
+  A.sums = static_cast<const double*>(sums_dev);
+  A.rank = rank;
+  A.world = world;
   A.m0 = m0;
   A.m1 = m1;
   A.rng_state = rng_state48;
   A.jump = e->jump;
-  A.keys = e->d_keys.p;
-  A.src_index = e->d_src_index.p;
-  A.miss_flag = e->d_flags.p;
-  A.cdf_offset = cdf_offset;
-  A.sharded = 1;
-  A.is_last_shard = is_last_shard;
-  if (w > 0)
-  {
-    ProfScope ps(e, BPF_K_DRAW);
-    hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(w, 256)), dim3(256), 0, e->stream, A);
-  }
+  A.window = static_cast<long long*>(window_dev);
+  A.stride = stride;
+  A.flags = static_cast<int*>(flags_dev);
+  ProfScope ps(e, BPF_K_DRAW);
+  hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(m1 - m0, 256)), dim3(256), 0, e->stream, A);
   HIPCHK(e, hipGetLastError());
-  std::vector<int> src((size_t)std::max(w, 1)), keys((size_t)std::max(w, 1) * 3);
-  HIPCHK(e, hipMemcpyAsync(src.data(), e->d_src_index.p, (size_t)w * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_keys.p, (size_t)w * 3 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipMemcpyAsync(e->h_flags.p, e->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  // gather the selected poses on the host side of the shard (small: only this shard's hits)
-  std::vector<int> picked;
-  for (int o = 0; o < w; ++o)
-    if (src[o] >= 0)
-      picked.push_back(o);
-  if ((int)picked.size() > capacity)
-    return e->fail(BPF_ERR_CAPACITY, "draw_select output too small");
-  // poses: copy x/y/theta of the picked sources
-  std::vector<double> hx(e->sample_count), hy(e->sample_count), ht(e->sample_count);
-  if (!picked.empty())
-  {
-    HIPCHK(e, hipMemcpyAsync(hx.data(), a.x.p, (size_t)e->sample_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(hy.data(), a.y.p, (size_t)e->sample_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(ht.data(), a.th.p, (size_t)e->sample_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-  }
-  for (size_t q = 0; q < picked.size(); ++q)
-  {
-    const int o = picked[q];
-    draw_index_out[q] = m0 + o;
-    poses_out[3 * q] = hx[src[o]];
-    poses_out[3 * q + 1] = hy[src[o]];
-    poses_out[3 * q + 2] = ht[src[o]];
-    keys_out[3 * q] = keys[3 * o];
-    keys_out[3 * q + 1] = keys[3 * o + 1];
-    keys_out[3 * q + 2] = keys[3 * o + 2];
-  }
-  *count_out = (int)picked.size();
-  if (miss_out)
-    *miss_out = e->h_flags.p[0];
   return BPF_OK;
+}
+
+int bpf_shard_adopt_dev(bpf_engine* e, const void* x_dev, const void* y_dev, const void* theta_dev, int count,
+                        int global_count, int leaf_count, int bin_count)
+{
+  if (!e || !e->have_pf || count < 0 || global_count <= 0 || (count > 0 && (!x_dev || !y_dev || !theta_dev)))
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (count > e->max_samples)
+    return e->fail(BPF_ERR_CAPACITY, "adopted shard larger than max_samples");
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& b = e->sets[e->cur ^ 1];
+  if (count > 0)
+  {
+    ProfScope ps(e, BPF_K_FINALIZE);
+    hipLaunchKernelGGL(k_adopt, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream,
+                       static_cast<const double*>(x_dev), static_cast<const double*>(y_dev),
+                       static_cast<const double*>(theta_dev), b.dev(), count, 1.0 / (double)global_count);
+    HIPCHK(e, hipGetLastError());
+  }
+  e->cur ^= 1;
+  e->sample_count = count;
+  e->leaf_count = leaf_count;
+  e->bin_count = bin_count;
+  return BPF_OK;
+}
+
+int bpf_shard_converged_dev(bpf_engine* e, const void* x_all_dev, const void* y_all_dev, int global_count)
+{
+  if (!e || !e->have_pf || !x_all_dev || !y_all_dev || global_count <= 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  const double* x = static_cast<const double*>(x_all_dev);
+  const double* y = static_cast<const double*>(y_all_dev);
+  int rc = sum_into_slot(e, x, global_count, 3, 0, global_count);
+  if (rc != BPF_OK)
+    return rc;
+  rc = sum_into_slot(e, y, global_count, 4, 0, global_count);
+  if (rc != BPF_OK)
+    return rc;
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p + 1, 0, sizeof(int), e->stream));
+  const int grid = std::max(1, std::min(blocks_for(global_count, 256), 1024));
+  hipLaunchKernelGGL(k_count_converged, dim3(grid), dim3(256), 0, e->stream, x, y, global_count, e->d_scalars.p,
+                     e->dist_threshold, e->d_flags.p + 1);
+  HIPCHK(e, hipGetLastError());
+  e->converged_pending = true;
+  e->conv_n = global_count;
+  return BPF_OK;
+}
+
+uint64_t bpf_drand48_skip(uint64_t state48, uint64_t n)
+{
+  static LcgJump J;
+  static bool init = false;
+  if (!init)
+  {
+    lcg_tables(J);
+    init = true;
+  }
+  return lcg_skip_host(state48 & ((1ull << 48) - 1), n, J);
 }
 
 int bpf_kld_reset(bpf_engine* e)
@@ -1697,19 +1715,34 @@ int bpf_kld_reset(bpf_engine* e)
   if (!e)
     return BPF_ERR_INVALID_ARGUMENT;
   e->hist.clear();
+  e->seen.reset((size_t)std::min(std::max(e->max_samples, 1024), 1 << 20));
   return BPF_OK;
 }
 
-int bpf_kld_feed(bpf_engine* e, const int* keys, int n_keys, int first_draw_index, int* stop_count_out)
+int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys, int first_draw_index,
+                 int* stop_count_out)
 {
-  if (!e || !keys || !stop_count_out)
+  if (!e || !keys || !stop_count_out || stride < n_keys)
     return BPF_ERR_INVALID_ARGUMENT;
   *stop_count_out = -1;
+  const long long* k64 = static_cast<const long long*>(keys);
+  const int* k32 = static_cast<const int*>(keys);
+  int cached_leaf = -1, cached_limit = 0;
   for (int q = 0; q < n_keys; ++q)
   {
-    e->hist.insert(keys[3 * q], keys[3 * q + 1], keys[3 * q + 2]);
+    int k[3];
+    for (int d = 0; d < 3; ++d)
+      k[d] = keys_are_int64 ? (int)k64[(size_t)d * stride + q] : k32[(size_t)d * stride + q];
+    if (e->seen.first_time(k[0], k[1], k[2]))
+      e->hist.insert(k[0], k[1], k[2]);
+    const int lc = e->hist.leaf_count();
+    if (lc != cached_leaf)
+    {
+      cached_leaf = lc;
+      cached_limit = resample_limit(lc, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+    }
     const int count = first_draw_index + q + 1;
-    if (count > resample_limit(e->hist.leaf_count(), e->min_samples, e->max_samples, e->pop_err, e->pop_z))
+    if (count > cached_limit)
     {
       *stop_count_out = count;
       break;

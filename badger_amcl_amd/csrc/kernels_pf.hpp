@@ -133,6 +133,42 @@ __global__ void k_normalize(double* __restrict__ w, int n, const FilterScalars* 
     w[i] = 1.0 / global_n;
 }
 
+// Sharded variant: the global total is the rank-ordered sum of the gathered per-shard totals;
+// thread 0 of block 0 also applies the running-average update with the global numbers.
+__global__ void k_normalize_gathered(double* __restrict__ w, int n, const double* __restrict__ totals, int world,
+                                     int global_n, FilterScalars* sc, double alpha_slow, double alpha_fast)
+{
+  double total = 0.0;
+  for (int r = 0; r < world; ++r)
+    total += totals[r];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0)
+  {
+    sc->v[6] = total;
+    if (total > 0.0)
+    {
+      const double w_avg = total / global_n;
+      double ws = sc->v[1], wf = sc->v[2];
+      if (ws == 0.0)
+        ws = w_avg;
+      else
+        ws += alpha_slow * (w_avg - ws);
+      if (wf == 0.0)
+        wf = w_avg;
+      else
+        wf += alpha_fast * (w_avg - wf);
+      sc->v[1] = ws;
+      sc->v[2] = wf;
+    }
+  }
+  if (i >= n)
+    return;
+  if (total > 0.0)
+    w[i] = w[i] / total;
+  else
+    w[i] = 1.0 / global_n;
+}
+
 // ------------------------------------------------------------------ CDF (inclusive scan)
 // c[0] = 0, c[i+1] = c[i] + w[i]  (particle_filter.cpp:372-375), evaluated as a fixed-shape
 // three-phase scan: per-2048-tile sums, scan of the tile sums by one block, then the
@@ -345,6 +381,88 @@ __global__ void k_draw_select(const DrawArgs A)
   }
   A.src_index[o] = i;
   pose_key(x, y, th, &A.keys[3 * o]);
+}
+
+// Sharded multinomial draws: every shard evaluates every draw of the window, keeps the ones whose
+// r falls into its slice [offset, offset + sums[rank]) of the global CDF (the slices partition
+// [0, total) exactly because every rank forms the same left-to-right running sum of `sums`),
+// and writes pose bits + histogram key as int64 rows; draws owned by another shard are zeroed.
+struct WindowArgs
+{
+  ParticlesDev src;
+  int n_src;
+  const double* cdf;     // local running sum, c[0] = 0
+  const double* sums;    // [world] per-shard CDF sums, rank order
+  int rank, world;
+  int m0, m1;
+  uint64_t rng_state;
+  LcgJump jump;
+  long long* window;     // [6][stride]
+  int stride;
+  int* flags;
+};
+
+__global__ void k_draw_window(const WindowArgs A)
+{
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = A.m0 + o;
+  if (m >= A.m1)
+    return;
+  double offset = 0.0;
+  for (int r = 0; r < A.rank; ++r)
+    offset += A.sums[r];
+  const double top = offset + A.sums[A.rank];
+  const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
+  const double r = ldexp((double)xs, -48);
+  const bool last = A.rank == A.world - 1;
+  const bool mine = (r >= offset) && (r < top || last);
+  long long out[6] = { 0, 0, 0, 0, 0, 0 };
+  if (mine)
+  {
+    int i;
+    if (!(r < top))
+    {
+      atomicExch(A.flags, 1);  // reference: ROS_ASSERT(i < sample_count)
+      i = A.n_src - 1;
+    }
+    else
+    {
+      int lo = 0, hi = A.n_src;  // offset + c[lo] <= r < offset + c[hi]
+      while (hi - lo > 1)
+      {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (offset + A.cdf[mid] <= r)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      i = lo;
+    }
+    const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
+    int key[3];
+    pose_key(x, y, th, key);
+    out[0] = __double_as_longlong(x);
+    out[1] = __double_as_longlong(y);
+    out[2] = __double_as_longlong(th);
+    out[3] = key[0];
+    out[4] = key[1];
+    out[5] = key[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    A.window[(size_t)k * A.stride + o] = out[k];
+}
+
+__global__ void k_adopt(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th,
+                        ParticlesDev dst, int n, double weight)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  dst.x[i] = x[i];
+  dst.y[i] = y[i];
+  dst.th[i] = th[i];
+  dst.w[i] = weight;
 }
 
 // Systematic resampler targets (particle_filter.cpp:326-341): target_0 = start, then

@@ -1,0 +1,210 @@
+"""One particle filter sharded over the GPUs of a node: one process per GPU, each engine holds a
+contiguous slice of the particle index space, `torch.distributed` (backend "nccl" = RCCL over
+xGMI) carries the three small exchanges the path really has:
+
+  update_sensor    all-gather of W per-shard weight totals (8 B each)
+  update_resample  all-gather of W per-shard CDF sums (8 B each), then per candidate-draw window
+                   one integer all-reduce(sum) of [6, window] int64 (pose bits + histogram key of
+                   every draw; exactly one shard writes each column, the others contribute 0)
+
+Scoring itself shards with no communication.  The KLD stop rule (an ordered kd-tree replay) runs
+redundantly on every rank from the assembled key window, so all ranks agree on the sample count
+without another exchange; the resampled set is re-split evenly in index order.
+
+`ShardedFilter` is backend-agnostic: `HipShardBackend` drives the C-ABI stage functions
+(bpf_shard_*); the CPU tests plug in a backend of their own over gloo.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+
+class _DevArray:
+    """Zero-copy view of engine-owned device memory for torch (cuda array interface v2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class HipShardBackend:
+    """Stage functions of include/badger_pf.h on one GPU.  Runs on torch's current stream so that
+    torch copies / RCCL collectives and engine kernels are ordered without host syncs."""
+
+    def __init__(self, engine, scanner, pf, device):
+        self.e, self.sc, self.pf = engine, scanner, pf
+        self.device = device
+        stream = torch.cuda.current_stream(device)
+        engine.set_stream(stream.cuda_stream)
+        p = C.c_void_p()
+        engine.check(engine.lib.bpf_shard_scalars_dev(engine.h, C.byref(p)))
+        self.scalars = torch.as_tensor(_DevArray(p.value, (16,), "<f8"), device=device)
+
+    def n_local(self):
+        return self.pf.getState().sample_count
+
+    def score(self, data):
+        lib, e = self.e.lib, self.e
+        e.check(lib.bpf_shard_score_planar(e.h, data.ranges_.ctypes.data_as(C.POINTER(C.c_double)),
+                                           data.angles_.ctypes.data_as(C.POINTER(C.c_double)), data.range_count_,
+                                           data.range_max_))
+
+    def local_total(self):
+        return self.scalars[0:1]
+
+    def normalize(self, totals, global_n):
+        e = self.e
+        e.check(e.lib.bpf_shard_normalize_dev(e.h, C.c_void_p(totals.data_ptr()), totals.numel(), int(global_n)))
+
+    def build_cdf(self):
+        self.e.check(self.e.lib.bpf_shard_build_cdf(self.e.h))
+
+    def local_sum(self):
+        return self.scalars[7:8]
+
+    def draw_window(self, rng, m0, m1, sums, rank, world, window, flags):
+        e = self.e
+        e.check(e.lib.bpf_shard_draw_window_dev(e.h, C.c_uint64(rng), m0, m1, C.c_void_p(sums.data_ptr()), rank, world,
+                                                C.c_void_p(window.data_ptr()), window.shape[1],
+                                                C.c_void_p(flags.data_ptr())))
+
+    def kld_reset(self):
+        self.e.check(self.e.lib.bpf_kld_reset(self.e.h))
+
+    def kld_feed(self, keys_cpu, n, first):
+        stop = C.c_int(-1)
+        k = keys_cpu.numpy()
+        assert k.dtype == np.int64 and k.flags.c_contiguous
+        self.e.check(self.e.lib.bpf_kld_feed(self.e.h, k.ctypes.data_as(C.c_void_p), 1, k.shape[1], n, first,
+                                             C.byref(stop)))
+        return stop.value
+
+    def kld_counts(self):
+        a, b = C.c_int(), C.c_int()
+        self.e.check(self.e.lib.bpf_kld_leaf_count(self.e.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def adopt(self, x, y, th, count, global_m, leaf, bins):
+        e = self.e
+        e.check(e.lib.bpf_shard_adopt_dev(e.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                          C.c_void_p(th.data_ptr()), count, global_m, leaf, bins))
+
+    def converged(self, x_all, y_all, m):
+        e = self.e
+        e.check(e.lib.bpf_shard_converged_dev(e.h, C.c_void_p(x_all.data_ptr()), C.c_void_p(y_all.data_ptr()), m))
+
+    def skip(self, state, n):
+        return int(self.e.lib.bpf_drand48_skip(C.c_uint64(state), C.c_uint64(n)))
+
+    def rng_state(self):
+        return self.pf.getRngState()
+
+    def set_rng_state(self, s):
+        self.pf.setRngState(s)
+
+    def max_samples(self):
+        return self.pf.max_samples
+
+    def state(self):
+        return self.pf.getState()
+
+
+class ShardedState:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class ShardedFilter:
+    """ParticleFilter::updateSensor / updateResample over W shards (see module docstring)."""
+
+    def __init__(self, backend, dist, rank=None, world=None, first_window=4096):
+        self.b = backend
+        self.dist = dist
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.device = backend.device
+        self.cpu_collectives = dist.get_backend() == "gloo" and torch.device(self.device).type != "cpu"
+        self.max_global = backend.max_samples()  # engines are created with the GLOBAL min / max sample counts
+        n = torch.tensor([backend.n_local()], dtype=torch.int64, device=self.device)
+        self.counts = [int(v) for v in self._all_gather(n).cpu().tolist()]
+        self.window_hint = first_window
+        self.out = torch.zeros((3, self.max_global), dtype=torch.float64, device=self.device)
+        self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._windows = {}
+        self.sample_count = sum(self.counts)
+        self.leaf_count = self.bin_count = 0
+        self.windows_used = 0
+
+    # ---- collectives (device tensors with nccl; staged through the host only for gloo + GPU)
+    def _all_gather(self, t):
+        src = t.cpu() if self.cpu_collectives else t
+        outs = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(outs, src.contiguous())
+        res = torch.cat(outs)
+        return res.to(self.device) if self.cpu_collectives else res
+
+    def _all_reduce_sum(self, t):
+        if self.cpu_collectives:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    # ---- Seam A
+    def update_sensor(self, data):
+        self.b.score(data)
+        totals = self._all_gather(self.b.local_total())
+        self.b.normalize(totals, self.sample_count)
+
+    # ---- Seam B (multinomial, w_diff == 0)
+    def update_resample(self):
+        b, W = self.b, self.world
+        b.build_cdf()
+        sums = self._all_gather(b.local_sum())
+        rng = b.rng_state()
+        b.kld_reset()
+        self.flags.zero_()
+        m0, stop = 0, -1
+        win = max(1024, min(self.window_hint, self.max_global))
+        self.windows_used = 0
+        while m0 < self.max_global and stop < 0:
+            m1 = min(self.max_global, m0 + win)
+            cnt = m1 - m0
+            window = self._windows.get(cnt)
+            if window is None:
+                window = torch.zeros((6, cnt), dtype=torch.int64, device=self.device)
+                self._windows[cnt] = window
+            b.draw_window(rng, m0, m1, sums, self.rank, W, window, self.flags)
+            self._all_reduce_sum(window)
+            self.out[:, m0:m1] = window[0:3].view(torch.float64)
+            keys = window[3:6].cpu().contiguous()  # the one host sync of the window
+            stop = b.kld_feed(keys, cnt, m0)
+            self.windows_used += 1
+            m0 = m1
+            win *= 4
+        M = stop if stop > 0 else self.max_global
+        leaf, bins = b.kld_counts()
+        lo, hi = (M * self.rank) // W, (M * (self.rank + 1)) // W
+        b.adopt(self.out[0, lo:hi], self.out[1, lo:hi], self.out[2, lo:hi], hi - lo, M, leaf, bins)
+        b.converged(self.out[0, :M], self.out[1, :M], M)
+        b.set_rng_state(b.skip(rng, 2 * M))
+        self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
+        self.sample_count = M
+        self.leaf_count, self.bin_count = leaf, bins
+        self.window_hint = max(1024, ((M + M // 4) + 1023) // 1024 * 1024)
+
+    def restore(self, counts):
+        """Bench helper: the shards were put back by pf.restore(); reset the bookkeeping."""
+        self.counts = list(counts)
+        self.sample_count = sum(counts)
+
+    def state(self):
+        st = self.b.state()
+        miss = self._all_reduce_sum(self.flags.clone())
+        return ShardedState(sample_count=self.sample_count, local_count=st.sample_count, leaf_count=self.leaf_count,
+                            bin_count=self.bin_count, converged=st.converged,
+                            percent_converged=st.percent_converged, w_slow=st.w_slow, w_fast=st.w_fast,
+                            total=st.total, cdf_miss=int(miss[0].item()) != 0, windows=self.windows_used)

@@ -71,7 +71,8 @@ def setup_engine(args, wl, device):
         sc.setModelBeam(p["z_hit"], p["z_short"], p["z_max"], p["z_rand"], p["sigma_hit"], p["lambda_short"])
     sc.setMapFactors(*synth.MAP_FACTORS)
     sc.setPlanarScannerPose(synth.SCANNER_POSE)
-    pf = bpf.ParticleFilter(e, 100, wl["n"], 0.0, 0.0, 85.0)
+    # sharded: every engine carries the GLOBAL min / max sample counts (the KLD bound is global)
+    pf = bpf.ParticleFilter(e, 100, wl["n"] * wl.get("world", 1), 0.0, 0.0, 85.0)
     pf.setResampleModel(1 if args.resampler == "systematic" else 0)
     pf.srand48(42)
     pf.initWithSamples(wl["samples"])
@@ -146,14 +147,18 @@ def main():
     torch.cuda.set_device(local_rank)
 
     wl = build_workload(args, rank)
+    wl["world"] = world
     e, m, sc, pf, data, lut = setup_engine(args, wl, local_rank)
 
     if world > 1:
-        from badger_amcl_amd.sharded import ShardedFilter
-        sf = ShardedFilter(e, sc, pf, dist, device=torch.device("cuda", local_rank))
+        from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+        backend = HipShardBackend(e, sc, pf, torch.device("cuda", local_rank))
+        sf = ShardedFilter(backend, dist)
+        shard_counts = list(sf.counts)
 
         def step():
             pf.restore()
+            sf.restore(shard_counts)
             sf.update_sensor(data)
             sf.update_resample()
     else:

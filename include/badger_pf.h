@@ -203,29 +203,48 @@ double bpf_cloud_apply_model_to_sample_set(bpf_engine* e, double* samples, int s
 int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_points);
 
 /* ------------------------------------------------------------------ sharded operation
- * One engine per GPU holds a contiguous shard of the particle set; the host exchanges
- * the few scalars / key lists between ranks (RCCL or any other transport) and calls
- * these stage functions.  All device work is asynchronous on the engine stream. */
-/* score + recalcWeight on the local shard; local total lands in device scalar slot 0 */
+ * One engine per GPU holds a contiguous shard (rank order = particle index order) of ONE
+ * filter.  Scoring needs no exchange; normalisation needs the per-shard weight totals;
+ * resampling needs the per-shard CDF sums and one sum-exchange of the candidate draw window.
+ * The exchanges themselves (RCCL all-gather / all-reduce over xGMI) are issued by the host
+ * layer on the same stream between these stage calls; every `_dev` pointer is device memory
+ * and nothing here synchronises with the host.  badger_amcl_amd/sharded.py is the driver. */
+/* score + recalcWeight on the local shard; the local weight total lands in scalars[0] */
 int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
                            double range_max);
-/* device address of the engine's scalar block: double[8]; [0] = local weight total */
+/* device address of the engine's scalar block, double[16]: [0] local weight total,
+ * [1] w_slow, [2] w_fast, [7] local CDF sum (after bpf_shard_build_cdf) */
 int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr);
-/* particle_filter.cpp:237-266 with the GLOBAL total and GLOBAL sample count */
-int bpf_shard_normalize(bpf_engine* e, double global_total, int global_sample_count);
-/* local running sum of weights (c[i+1] - c[0]); the host adds the lower ranks' sums */
-int bpf_shard_build_cdf(bpf_engine* e, double* local_sum_out);
-/* For global draws m in [m0, m1) of the multinomial resampler whose r falls in
- * [cdf_offset, cdf_offset + local_sum): source pose and histogram key.  Results are
- * compacted in draw order: draw_index[], pose xyz triples, key triples. */
-int bpf_shard_draw_select(bpf_engine* e, uint64_t rng_state48, int m0, int m1, double cdf_offset, int is_last_shard,
-                          int* draw_index_out, double* poses_out, int* keys_out, int capacity, int* count_out,
-                          int* miss_out);
+/* ParticleFilter::updateSensor's normalisation (particle_filter.cpp:237-266) with the global
+ * total = totals_dev[0] + ... + totals_dev[world-1] (added in rank order) and the global count */
+int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, int global_sample_count);
+/* local running sum c[0..n] of the shard's weights; its last element is copied to scalars[7] */
+int bpf_shard_build_cdf(bpf_engine* e);
+/* Candidate draws m in [m0, m1) of the multinomial resampler (particle_filter.cpp:381-414) from
+ * the drand48 state `rng_state48`.  The shard owns the draws whose r lies in
+ * [offset, offset + sums_dev[rank]) with offset = sums_dev[0] + ... + sums_dev[rank-1].
+ * window_dev is int64[6][stride]: rows 0-2 the bit patterns of the selected pose (x, y, theta),
+ * rows 3-5 its histogram key; column m - m0.  Owned draws are written, all others are zeroed, so
+ * an integer sum over the ranks assembles the window exactly.  flags_dev[0] is set on a CDF miss. */
+int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev, int rank,
+                              int world, void* window_dev, int stride, void* flags_dev);
+/* Become the resampled shard: copy `count` poses from device arrays, weight 1/global_count each
+ * (particle_filter.cpp:409,458-462), flip the ping-pong sets. */
+int bpf_shard_adopt_dev(bpf_engine* e, const void* x_dev, const void* y_dev, const void* theta_dev, int count,
+                        int global_count, int leaf_count, int bin_count);
+/* updateConverged (particle_filter.cpp:170-220) over the WHOLE resampled set (every rank holds it
+ * after the window exchange); fetched lazily by bpf_pf_get_state. */
+int bpf_shard_converged_dev(bpf_engine* e, const void* x_all_dev, const void* y_all_dev, int global_count);
+/* Advance a drand48 state by n draws (host arithmetic; the LCG jump the kernels use). */
+uint64_t bpf_drand48_skip(uint64_t state48, uint64_t n);
 /* Host-side exact KLD stop rule: replay ordered histogram keys through the fork's kd-tree
  * (pf_kdtree.cpp:97-150) and apply resampleLimit after each (particle_filter.cpp:416).
- * State persists in the engine between calls so windows can be fed one after another. */
+ * State persists in the engine between calls so windows can be fed one after another.
+ * keys: int64 triples when keys_are_int64 != 0 (the window rows), else int32 triples, laid out
+ * as three rows of `stride` (row-major [3][stride]). */
 int bpf_kld_reset(bpf_engine* e);
-int bpf_kld_feed(bpf_engine* e, const int* keys, int n_keys, int first_draw_index, int* stop_count_out);
+int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys, int first_draw_index,
+                 int* stop_count_out);
 int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out);
 
 /* ------------------------------------------------------------------ measurement */

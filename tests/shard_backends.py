@@ -1,0 +1,163 @@
+"""Test-only shard backend: the same stage interface as badger_amcl_amd.sharded.HipShardBackend,
+implemented with the CPU oracle, so that ShardedFilter's exchange logic (rank-ordered totals,
+CDF slices, window assembly, even re-split) runs under gloo with world_size 2 and no GPU."""
+import numpy as np
+import torch
+
+MASK48 = (1 << 48) - 1
+LCG_A, LCG_C = 0x5DEECE66D, 0xB
+
+
+def lcg_skip(state, n):
+    a, c = 1, 0
+    pa, pc = LCG_A, LCG_C
+    while n:
+        if n & 1:
+            a, c = (a * pa) & MASK48, (c * pa + pc) & MASK48
+        pc = (pc * pa + pc) & MASK48
+        pa = (pa * pa) & MASK48
+        n >>= 1
+    return (a * state + c) & MASK48
+
+
+class OracleShardBackend:
+    device = "cpu"
+
+    def __init__(self, orc, omap, planar, samples, min_samples, max_samples_global, seed, alpha=(0.0, 0.0)):
+        self.orc, self.omap, self.planar = orc, omap, planar
+        self.samples = np.ascontiguousarray(samples, dtype=np.float64).copy()
+        self.pfh = orc.ParticleFilter(min_samples, max_samples_global, alpha[0], alpha[1], 85.0, seed=seed)
+        self._max = max_samples_global
+        self._total = torch.zeros(1, dtype=torch.float64)
+        self._sum = torch.zeros(1, dtype=torch.float64)
+        self.tree = None
+        self.leaf = self.bins = 0
+        self.conv = 0
+
+    def n_local(self):
+        return self.samples.shape[0]
+
+    def max_samples(self):
+        return self._max
+
+    def score(self, data):
+        ranges, angles, range_max = data
+        if self.samples.shape[0]:
+            self.orc.planar_apply(self.planar, self.omap, self.samples, ranges, angles, range_max, 0)
+        t = 0.0
+        for w in self.samples[:, 3]:
+            t += w
+        self._total[0] = t
+
+    def local_total(self):
+        return self._total
+
+    def normalize(self, totals, global_n):
+        T = 0.0
+        for v in totals.tolist():
+            T += v
+        pf = self.pfh.pf
+        if T > 0.0:
+            self.samples[:, 3] /= T
+            w_avg = T / global_n
+            pf.w_slow = w_avg if pf.w_slow == 0.0 else pf.w_slow + pf.alpha_slow * (w_avg - pf.w_slow)
+            pf.w_fast = w_avg if pf.w_fast == 0.0 else pf.w_fast + pf.alpha_fast * (w_avg - pf.w_fast)
+        else:
+            self.samples[:, 3] = 1.0 / global_n
+
+    def build_cdf(self):
+        c = np.zeros(self.samples.shape[0] + 1)
+        run = 0.0
+        for i, w in enumerate(self.samples[:, 3]):
+            run = run + w
+            c[i + 1] = run
+        self.cdf = c
+        self._sum[0] = c[-1]
+
+    def local_sum(self):
+        return self._sum
+
+    def draw_window(self, rng, m0, m1, sums, rank, world, window, flags):
+        s = sums.tolist()
+        offset = 0.0
+        for r in range(rank):
+            offset += s[r]
+        top = offset + s[rank]
+        window.zero_()
+        w = window.numpy()
+        n = self.samples.shape[0]
+        cell_th = 10 * np.pi / 180
+        for m in range(m0, m1):
+            x = lcg_skip(rng, 2 * m + 2)
+            r = x / float(1 << 48)
+            mine = r >= offset and (r < top or rank == world - 1)
+            if not mine:
+                continue
+            if not r < top:
+                flags[0] = 1
+                i = n - 1
+            else:
+                lo, hi = 0, n
+                while hi - lo > 1:
+                    mid = (lo + hi) // 2
+                    if offset + self.cdf[mid] <= r:
+                        lo = mid
+                    else:
+                        hi = mid
+                i = lo
+            p = self.samples[i, :3]
+            o = m - m0
+            w[0:3, o] = p.view(np.int64)
+            w[3, o] = int(np.floor(p[0] / 0.5))
+            w[4, o] = int(np.floor(p[1] / 0.5))
+            w[5, o] = int(np.floor(p[2] / cell_th))
+
+    def kld_reset(self):
+        self.tree = self.orc.KDTree()
+
+    def kld_feed(self, keys, n, first):
+        k = keys.numpy()
+        for q in range(n):
+            self.tree.insert_key(k[:, q].astype(np.int32), 1.0)
+            count = first + q + 1
+            if count > self.pfh.resample_limit(self.tree.leaf_count()):
+                return count
+        return -1
+
+    def kld_counts(self):
+        return self.tree.leaf_count(), self.tree.node_count()
+
+    def adopt(self, x, y, th, count, global_m, leaf, bins):
+        s = np.zeros((count, 4))
+        s[:, 0], s[:, 1], s[:, 2] = x.numpy(), y.numpy(), th.numpy()
+        s[:, 3] = 1.0 / global_m
+        self.samples = s
+        self.leaf, self.bins = leaf, bins
+
+    def converged(self, x_all, y_all, m):
+        s = np.zeros((m, 4))
+        s[:, 0], s[:, 1] = x_all.numpy(), y_all.numpy()
+        import ctypes as C
+        pct = C.c_float()
+        self.conv = self.orc.lib().orc_pf_update_converged(C.byref(self.pfh.pf), s.ctypes.data_as(
+            C.POINTER(C.c_double)), m, C.byref(pct))
+        self.pct = pct.value
+
+    def skip(self, state, n):
+        return lcg_skip(state, n)
+
+    def rng_state(self):
+        return int(self.pfh.pf.rng)
+
+    def set_rng_state(self, s):
+        self.pfh.pf.rng = s
+
+    def state(self):
+        class S:
+            pass
+        st = S()
+        st.sample_count = self.samples.shape[0]
+        st.converged, st.percent_converged = self.conv, getattr(self, "pct", 0.0)
+        st.w_slow, st.w_fast = self.pfh.pf.w_slow, self.pfh.pf.w_fast
+        st.total = float(self._total[0])
+        return st

@@ -1,0 +1,94 @@
+"""GPU test of the sharded path: two ranks share cuda:0 (gloo carries the exchanges, staged
+through the host), each drives the bpf_shard_* stage functions on its half of the set; together
+they must reproduce the single-engine result, which the other gpu tests tie to the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scenario():
+    from oracle import pyoracle as orc
+    from scenario import Scenario
+    return orc, Scenario(orc, size=400, n=6000, beams=181, cloud="converged")
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import badger_amcl_amd as bpf
+    from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+    orc, sc = _scenario()
+    n = sc.samples.shape[0]
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    e = bpf.Engine(0)
+    shard = Scenario.__new__(Scenario)
+    shard.__dict__.update(sc.__dict__)
+    shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
+    m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    b = HipShardBackend(e, scn, pf, torch.device("cuda", 0))
+    sf = ShardedFilter(b, dist, first_window=1024)
+    recs = []
+    for cycle in range(2):
+        sf.update_sensor(data)
+        w_after = pf.getCurrentSet().samples.copy()
+        sf.update_resample()
+        st = sf.state()
+        recs.append(dict(w=w_after, samples=pf.getCurrentSet().samples.copy(), M=st.sample_count, leaf=st.leaf_count,
+                         bins=st.bin_count, rng=pf.getRngState(), conv=st.converged, miss=st.cdf_miss,
+                         w_slow=st.w_slow))
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(recs, dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    e.close()
+
+
+def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
+
+    import badger_amcl_amd as bpf
+    orc, sc = _scenario()
+    n = sc.samples.shape[0]
+    e = bpf.Engine(0)
+    m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    for cycle in range(2):
+        scn.updateSensor(pf, data)
+        w_ref = pf.getCurrentSet().samples[:, 3].copy()
+        pf.updateResample()
+        st = pf.getState()
+        cur = pf.getCurrentSet()
+        r0, r1 = recs[0][cycle], recs[1][cycle]
+        w_sh = np.concatenate([r0["w"][:, 3], r1["w"][:, 3]])
+        assert np.allclose(w_sh, w_ref, rtol=1e-12, atol=0)
+        for r in (r0, r1):
+            assert r["M"] == st.sample_count and r["leaf"] == st.leaf_count and r["bins"] == st.bin_count
+            assert r["rng"] == pf.getRngState()
+            assert r["conv"] == st.converged and not r["miss"]
+        merged = np.concatenate([r0["samples"], r1["samples"]])
+        assert np.array_equal(merged[:, :3], cur.samples[:, :3])
+        assert np.all(merged[:, 3] == 1.0 / st.sample_count)
+    e.close()
