@@ -989,7 +989,7 @@ int bpf_set_stream(bpf_engine* e, void* hip_stream)
   if (!e)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
+  e->stream = (hip_stream == BPF_OWN_STREAM) ? e->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
   return BPF_OK;
 }
 

@@ -63,7 +63,10 @@ class Engine:
                            self.lib.bpf_error_string(rc).decode())
 
     def set_stream(self, hip_stream):
-        self.check(self.lib.bpf_set_stream(self.h, C.c_void_p(hip_stream)))
+        """hip_stream: a hipStream_t handle as an int (0 = HIP's default stream), or None for the
+        engine's own stream."""
+        handle = C.c_void_p(-1) if hip_stream is None else C.c_void_p(hip_stream)
+        self.check(self.lib.bpf_set_stream(self.h, handle))
 
     def synchronize(self):
         self.check(self.lib.bpf_synchronize(self.h))

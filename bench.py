@@ -132,14 +132,24 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
 
+    # Native libraries (RCCL prints a version banner) write to fd 1; keep the real stdout for the
+    # one JSON line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("BPF_FORCE_SHARDED") == "1"  # exercise the sharded path at world 1
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -150,7 +160,7 @@ def main():
     wl["world"] = world
     e, m, sc, pf, data, lut = setup_engine(args, wl, local_rank)
 
-    if world > 1:
+    if dist is not None:
         from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
         backend = HipShardBackend(e, sc, pf, torch.device("cuda", local_rank))
         sf = ShardedFilter(backend, dist)
@@ -187,7 +197,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = e.profile_get()
     e.profile_enable(False)
-    st = pf.getState() if world == 1 else sf.state()
+    st = pf.getState() if dist is None else sf.state()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -241,7 +251,7 @@ def main():
         }
         if mean_cells is not None:
             line["roofline"]["mean_cells_per_ray"] = mean_cells
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -70,7 +70,10 @@ int bpf_create(int device_ordinal, bpf_engine** out);
 void bpf_destroy(bpf_engine* e);
 const char* bpf_error_string(int code);
 const char* bpf_last_error_message(const bpf_engine* e);
-/* Run the engine's work on a caller-provided hipStream_t (NULL restores its own). */
+/* Run the engine's work on a caller-provided hipStream_t.  NULL is HIP's default (null) stream,
+ * which is what torch.cuda.current_stream().cuda_stream reports unless a side stream is active;
+ * BPF_OWN_STREAM restores the engine's own non-blocking stream. */
+#define BPF_OWN_STREAM ((void*)(intptr_t)-1)
 int bpf_set_stream(bpf_engine* e, void* hip_stream);
 int bpf_synchronize(bpf_engine* e);
 

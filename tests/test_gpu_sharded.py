@@ -38,6 +38,7 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     import badger_amcl_amd as bpf
     from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+    from scenario import Scenario
     orc, sc = _scenario()
     n = sc.samples.shape[0]
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
