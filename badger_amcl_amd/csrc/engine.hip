@@ -13,6 +13,7 @@
 #include "../../include/badger_pf.h"
 #include "device_types.hpp"
 #include "kdhist.hpp"
+#include "kernels_cloud.hpp"
 #include "kernels_pf.hpp"
 #include "kernels_score.hpp"
 
@@ -148,6 +149,21 @@ struct bpf_engine
   int ring_next = 0;
   DevBuf<int> d_obs_count;
   DevBuf<unsigned long long> d_cells_walked;
+
+  // ---- 3-D map + point-cloud scanner
+  bool have_map3d = false;
+  Map3dDev map3{};
+  double map3_max_dist = 0.0;
+  DevBuf<uint32_t> d_pose_indices;
+  DevBuf<uint8_t> d_ratios;
+  bool cloud_configured = false;
+  int cloud_max_beams = 0;
+  double cloud_z_hit = 0, cloud_z_rand = 0, cloud_sigma = 0;
+  CloudModelDev cm{};
+  DevBuf<float> d_affine, d_points;
+  DevBuf<double> d_cloud_partials, d_cloud_table;
+  PinnedBuf<float> h_points;
+  PinnedBuf<double> h_cloud_table;
 
   // ---- particle filter
   bool have_pf = false;
@@ -953,6 +969,8 @@ void bpf_destroy(bpf_engine* e)
   e->d_lut_tiles.release(); e->d_notfree.release(); e->d_cells8.release(); e->d_levels.release();
   e->d_lut_f32.release(); e->d_edt_tmp.release(); e->d_obs_count.release();
   e->d_cells_walked.release();
+  e->d_pose_indices.release(); e->d_ratios.release(); e->d_affine.release(); e->d_points.release();
+  e->d_cloud_partials.release(); e->d_cloud_table.release(); e->h_points.release(); e->h_cloud_table.release();
   e->sets[0].release(); e->sets[1].release(); e->scratch.release(); e->snap.release();
   e->d_cdf.release(); e->d_partials.release(); e->d_targets.release(); e->d_scalars.release();
   e->d_keys.release(); e->d_src_index.release(); e->d_flags.release(); e->d_aos.release();
@@ -1528,40 +1546,244 @@ int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out)
   return BPF_OK;
 }
 
-// ---------------------------------------------------------------------- 3-D (next milestone)
-int bpf_map3d_set(bpf_engine* e, const uint32_t*, size_t, const uint8_t*, size_t, const int*, const int*, double,
-                  double)
+// ---------------------------------------------------------------------- 3-D map + point cloud
+int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_indices, const uint8_t* distance_ratios,
+                  size_t n_distance_ratios, const int min_cells[3], const int max_cells[3], double resolution,
+                  double max_dist)
 {
-  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : BPF_ERR_INVALID_ARGUMENT;
+  if (!e || !pose_indices || !distance_ratios || !min_cells || !max_cells || !(resolution > 0) || !(max_dist > 0))
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad 3-D map arguments") : BPF_ERR_INVALID_ARGUMENT;
+  const long long w = (long long)max_cells[0] - min_cells[0] + 1, h = (long long)max_cells[1] - min_cells[1] + 1,
+                  nz = (long long)max_cells[2] - min_cells[2] + 1;
+  if (w <= 0 || h <= 0 || nz <= 0 || (size_t)(w * h) != n_pose_indices)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "pose_indices size does not match the cell bounds");
+  // every column start must leave room for a whole z column (octomap.cpp:315-333)
+  for (size_t i = 0; i < n_pose_indices; ++i)
+    if ((size_t)pose_indices[i] + (size_t)nz > n_distance_ratios)
+      return e->fail(BPF_ERR_INVALID_ARGUMENT, "pose_indices entry points past distance_ratios");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, e->d_pose_indices.reserve(n_pose_indices));
+  HIPCHK(e, e->d_ratios.reserve(n_distance_ratios));
+  HIPCHK(e, hipMemcpy(e->d_pose_indices.p, pose_indices, n_pose_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(e->d_ratios.p, distance_ratios, n_distance_ratios, hipMemcpyHostToDevice));
+  Map3dDev& M = e->map3;
+  M.pose_indices = e->d_pose_indices.p;
+  M.distance_ratios = e->d_ratios.p;
+  for (int d = 0; d < 3; ++d)
+  {
+    M.min_c[d] = min_cells[d];
+    M.max_c[d] = max_cells[d];
+  }
+  M.width = (int)w;
+  M.resolution = resolution;
+  M.inv_resolution = 1.0 / resolution;
+  e->map3_max_dist = max_dist;
+  e->have_map3d = true;
+  return BPF_OK;
 }
-int bpf_cloud_init(bpf_engine* e, int) { return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1; }
-int bpf_cloud_set_model(bpf_engine* e, double, double, double)
+
+int bpf_cloud_init(bpf_engine* e, int max_beams)
 {
-  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cloud_max_beams = max_beams;
+  if (!e->cloud_configured)
+  {
+    e->cm.off_map_factor = 1.0;  // point_cloud_scanner.cpp:36-38
+    e->cm.tf_quat[3] = 1.0;
+  }
+  return BPF_OK;
 }
-int bpf_cloud_set_model_gompertz(bpf_engine* e, double, double, double, double, double, double, double, double, double)
+
+int bpf_cloud_set_model(bpf_engine* e, double z_hit, double z_rand, double sigma_hit)
 {
-  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cm.model = BPF_CLOUD_MODEL;
+  e->cloud_z_hit = z_hit;
+  e->cloud_z_rand = z_rand;
+  e->cloud_sigma = sigma_hit;
+  e->cloud_configured = true;
+  return BPF_OK;
 }
-int bpf_cloud_set_map_factors(bpf_engine* e, double, double, double)
+
+int bpf_cloud_set_model_gompertz(bpf_engine* e, double z_hit, double z_rand, double sigma_hit, double gompertz_a,
+                                 double gompertz_b, double gompertz_c, double input_shift, double input_scale,
+                                 double output_shift)
 {
-  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cm.model = BPF_CLOUD_MODEL_GOMPERTZ;
+  e->cm.g = GompertzDev{ gompertz_a, gompertz_b, gompertz_c, input_shift, input_scale, output_shift };
+  e->cloud_z_hit = z_hit;
+  e->cloud_z_rand = z_rand;
+  e->cloud_sigma = sigma_hit;
+  e->cloud_configured = true;
+  return BPF_OK;
 }
-int bpf_cloud_set_scanner_to_footprint_tf(bpf_engine* e, const double*, const double*)
+
+int bpf_cloud_set_map_factors(bpf_engine* e, double off_map_factor, double, double)
 {
-  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cm.off_map_factor = off_map_factor;  // the 3-D recalcWeight only uses this one (:205-229)
+  return BPF_OK;
 }
-double bpf_cloud_apply_model_to_sample_set(bpf_engine* e, double*, int, const float*, int, int* status)
+
+int bpf_cloud_set_scanner_to_footprint_tf(bpf_engine* e, const double xyz[3], const double quat_xyzw[4])
 {
-  if (status)
-    *status = BPF_ERR_UNSUPPORTED;
-  if (e)
-    e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet");
-  return 0.0;
+  if (!e || !xyz || !quat_xyzw)
+    return BPF_ERR_INVALID_ARGUMENT;
+  std::memcpy(e->cm.tf_xyz, xyz, 3 * sizeof(double));
+  std::memcpy(e->cm.tf_quat, quat_xyzw, 4 * sizeof(double));
+  return BPF_OK;
 }
-int bpf_pf_update_sensor_cloud(bpf_engine* e, const float*, int)
+
+namespace
 {
-  return e ? e->fail(BPF_ERR_UNSUPPORTED, "3-D path not built yet") : 1;
+int score_cloud(bpf_engine* e, ParticlesDev p, int n, const float* points_xyz, int n_points)
+{
+  if (!e->have_map3d)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 3-D map set");
+  if (!e->cloud_configured)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "point-cloud model not set");
+  if (!points_xyz || n_points <= 0 || n <= 0)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "empty cloud or sample set");
+  // stage points as float SoA; the table of per-ratio terms follows point_cloud_scanner.cpp:137-159,177-191
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // staging buffers are single-slot
+  HIPCHK(e, e->h_points.reserve((size_t)n_points * 3));
+  HIPCHK(e, e->d_points.reserve((size_t)n_points * 3));
+  for (int q = 0; q < n_points; ++q)
+  {
+    e->h_points.p[q] = points_xyz[3 * q];
+    e->h_points.p[(size_t)n_points + q] = points_xyz[3 * q + 1];
+    e->h_points.p[2 * (size_t)n_points + q] = points_xyz[3 * q + 2];
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_points.p, e->h_points.p, (size_t)n_points * 3 * sizeof(float), hipMemcpyHostToDevice,
+                           e->stream));
+  HIPCHK(e, e->h_cloud_table.reserve(257));
+  HIPCHK(e, e->d_cloud_table.reserve(257));
+  const double denom = 2 * e->cloud_sigma * e->cloud_sigma;
+  const double max_dist = e->map3_max_dist;
+  const double rand_mult = 1.0 / max_dist;  // :140: 1/max_distance, not 1/range_max
+  const double ratio = max_dist / 255;      // max_distance_ratio_, octomap.cpp:58
+  for (int k = 0; k <= 256; ++k)
+  {
+    const double z = (k == 256) ? max_dist : k * ratio;
+    double pz = e->cloud_z_hit * std::exp(-(z * z) / denom);
+    if (e->cm.model == BPF_CLOUD_MODEL)
+    {
+      pz += e->cloud_z_rand * rand_mult;
+      e->h_cloud_table.p[k] = pz * pz * pz;
+    }
+    else
+    {
+      pz += e->cloud_z_rand;
+      e->h_cloud_table.p[k] = pz;
+    }
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_cloud_table.p, e->h_cloud_table.p, 257 * sizeof(double), hipMemcpyHostToDevice,
+                           e->stream));
+  const int n_chunks = blocks_for(n_points, kCloudChunk);
+  HIPCHK(e, e->d_affine.reserve((size_t)n * 12));
+  HIPCHK(e, e->d_cloud_partials.reserve((size_t)n_chunks * n));
+  hipLaunchKernelGGL(k_cloud_affine, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, p, n, e->cm, e->d_affine.p);
+  CloudScoreArgs A{};
+  A.n = n;
+  A.affine = e->d_affine.p;
+  A.points = e->d_points.p;
+  A.n_points = n_points;
+  A.map = e->map3;
+  A.table = e->d_cloud_table.p;
+  A.partials = e->d_cloud_partials.p;
+  A.slabs = std::max(1, std::min(blocks_for(n, 4), std::max(1, (e->n_cu * 3) / n_chunks)));
+  {
+    ProfScope ps(e, BPF_K_SCORE);
+    hipLaunchKernelGGL(k_cloud_score, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
+  }
+  CloudFinishArgs F{};
+  F.p = p;
+  F.n = n;
+  F.partials = e->d_cloud_partials.p;
+  F.n_chunks = n_chunks;
+  F.n_points = n_points;
+  F.map = e->map3;
+  F.model = e->cm;
+  hipLaunchKernelGGL(k_cloud_finish, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, F);
+  HIPCHK(e, hipGetLastError());
+  e->evals_last = (long long)n * n_points;
+  return BPF_OK;
+}
+}  // namespace
+
+double bpf_cloud_apply_model_to_sample_set(bpf_engine* e, double* samples, int sample_count, const float* points_xyz,
+                                           int n_points, int* status)
+{
+  int dummy;
+  if (!status)
+    status = &dummy;
+  *status = BPF_OK;
+  if (!e || !samples)
+  {
+    *status = BPF_ERR_INVALID_ARGUMENT;
+    return 0.0;
+  }
+  if (e->cloud_max_beams < 2)
+    return 0.0;  // point_cloud_scanner.cpp:109-110
+  auto bail = [&](int code) { *status = code; return 0.0; };
+  if (hipSetDevice(e->device) != hipSuccess)
+    return bail(e->fail(BPF_ERR_HIP, "hipSetDevice"));
+  int rc = ensure_scalars(e);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = upload_samples(e, samples, sample_count, e->scratch);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = score_cloud(e, e->scratch.dev(), sample_count, points_xyz, n_points);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = sum_into_slot(e, e->scratch.w.p, sample_count, 0, 0, sample_count);
+  if (rc != BPF_OK)
+    return bail(rc);
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(sample_count, 256)), dim3(256), 0, e->stream, e->scratch.dev(),
+                     e->d_aos.p, sample_count);
+  if (hipMemcpyAsync(e->h_aos.p, e->d_aos.p, (size_t)sample_count * sizeof(double4), hipMemcpyDeviceToHost,
+                     e->stream) != hipSuccess ||
+      hipMemcpyAsync(e->h_scalars.p, e->d_scalars.p, sizeof(FilterScalars), hipMemcpyDeviceToHost, e->stream) !=
+          hipSuccess ||
+      hipStreamSynchronize(e->stream) != hipSuccess)
+    return bail(e->fail(BPF_ERR_HIP, "copy back"));
+  for (int i = 0; i < sample_count; ++i)
+    samples[4 * i + 3] = e->h_aos.p[i].w;
+  return e->h_scalars.p->v[0];
+}
+
+int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_points)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  if (e->cloud_max_beams < 2)
+    return BPF_OK;  // PointCloudScanner::updateSensor returns false (:95-96)
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& s = e->sets[e->cur];
+  const int n = e->sample_count;
+  int rc = score_cloud(e, s.dev(), n, points_xyz, n_points);
+  if (rc != BPF_OK)
+    return rc;
+  rc = sum_into_slot(e, s.w.p, n, 0, 1, n);
+  if (rc != BPF_OK)
+    return rc;
+  {
+    ProfScope ps(e, BPF_K_NORMALIZE);
+    hipLaunchKernelGGL(k_normalize, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.w.p, n, e->d_scalars.p, 0,
+                       0.0, n);
+  }
+  HIPCHK(e, hipGetLastError());
+  e->last_status = BPF_OK;
+  return BPF_OK;
 }
 
 // ---------------------------------------------------------------------- sharded stages
@@ -1849,6 +2071,8 @@ int bpf_profile_get(bpf_engine* e, bpf_profile* out)
 
 const char* bpf_score_kernel_name(const bpf_engine* e)
 {
+  if (e && !e->pm.configured && e->cloud_configured)
+    return "k_cloud_score";
   if (e && e->pm.model == BPF_MODEL_BEAM)
     return "k_score_beam";
   return "k_score_field";

@@ -320,3 +320,82 @@ class PlanarScanner:
         if status.value != 0:
             self.e.check(status.value)
         return total
+
+
+# --------------------------------------------------------------------------------- 3-D
+class OctoMap:
+    """LUT state of the reference OctoMap (include/amcl/map/octomap.h:96-110): pose_indices_,
+    distance_ratios_, cropped min/max cells.  Building it from an octree is the caller's job."""
+
+    def __init__(self, engine, resolution):
+        self.e = engine
+        self.resolution = float(resolution)
+
+    def setDistancesLUT(self, pose_indices, distance_ratios, min_cells, max_cells, max_distance_to_object):
+        pi = np.ascontiguousarray(pose_indices, dtype=np.uint32)
+        dr = np.ascontiguousarray(distance_ratios, dtype=np.uint8)
+        mn = np.ascontiguousarray(min_cells, dtype=np.int32)
+        mx = np.ascontiguousarray(max_cells, dtype=np.int32)
+        self.max_distance_to_object = float(max_distance_to_object)
+        self.e.check(self.e.lib.bpf_map3d_set(self.e.h, pi.ctypes.data_as(C.POINTER(C.c_uint32)), pi.size,
+                                              dr.ctypes.data_as(C.POINTER(C.c_uint8)), dr.size,
+                                              mn.ctypes.data_as(C.POINTER(C.c_int)),
+                                              mx.ctypes.data_as(C.POINTER(C.c_int)), self.resolution,
+                                              self.max_distance_to_object))
+
+
+class PointCloudData:
+    """include/amcl/sensors/point_cloud_scanner.h:45-51 (points_ as packed float xyz)"""
+
+    def __init__(self, points_xyz):
+        self.points_ = np.ascontiguousarray(points_xyz, dtype=np.float32).reshape(-1, 3)
+
+
+class PointCloudScanner:
+    """include/amcl/sensors/point_cloud_scanner.h:53-120"""
+
+    def __init__(self, engine):
+        self.e = engine
+        self.max_beams = 0
+
+    def init(self, max_beams, octomap):
+        self.max_beams = max_beams
+        self.map = octomap
+        self.e.check(self.e.lib.bpf_cloud_init(self.e.h, max_beams))
+
+    def setPointCloudModel(self, z_hit, z_rand, sigma_hit):
+        self.e.check(self.e.lib.bpf_cloud_set_model(self.e.h, z_hit, z_rand, sigma_hit))
+
+    def setPointCloudModelGompertz(self, z_hit, z_rand, sigma_hit, gompertz_a, gompertz_b, gompertz_c, input_shift,
+                                   input_scale, output_shift):
+        self.e.check(self.e.lib.bpf_cloud_set_model_gompertz(self.e.h, z_hit, z_rand, sigma_hit, gompertz_a,
+                                                             gompertz_b, gompertz_c, input_shift, input_scale,
+                                                             output_shift))
+
+    def setMapFactors(self, off_map_factor, non_free_space_factor, non_free_space_radius):
+        self.e.check(self.e.lib.bpf_cloud_set_map_factors(self.e.h, off_map_factor, non_free_space_factor,
+                                                          non_free_space_radius))
+
+    def setPointCloudScannerToFootprintTF(self, xyz, quat_xyzw):
+        t = np.ascontiguousarray(xyz, dtype=np.float64)
+        q = np.ascontiguousarray(quat_xyzw, dtype=np.float64)
+        self.e.check(self.e.lib.bpf_cloud_set_scanner_to_footprint_tf(self.e.h, _dp(t), _dp(q)))
+
+    def updateSensor(self, pf, data):
+        if self.max_beams < 2:
+            return False
+        pts = data.points_
+        self.e.check(self.e.lib.bpf_pf_update_sensor_cloud(self.e.h, pts.ctypes.data_as(C.POINTER(C.c_float)),
+                                                           pts.shape[0]))
+        return True
+
+    def applyModelToSampleSet(self, data, samples):
+        assert samples.dtype == np.float64 and samples.flags.c_contiguous
+        status = C.c_int(0)
+        pts = data.points_
+        total = self.e.lib.bpf_cloud_apply_model_to_sample_set(self.e.h, _dp(samples), samples.shape[0],
+                                                               pts.ctypes.data_as(C.POINTER(C.c_float)),
+                                                               pts.shape[0], C.byref(status))
+        if status.value != 0:
+            self.e.check(status.value)
+        return total

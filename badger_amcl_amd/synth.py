@@ -100,3 +100,50 @@ GOMPERTZ_LAUNCH = dict(z_hit=0.5, z_rand=0.5, sigma_hit=0.05, gompertz_a=0.941, 
                        input_shift=-0.97, input_scale=2.0, output_shift=0.25)    # badger_amcl_2d.launch:69-123
 MAP_FACTORS = (0.95, 0.95, 0.3)                                                   # badger_amcl_2d.launch:125-129
 SCANNER_POSE = (0.1, 0.0, 0.0)
+
+
+# 3-D ----------------------------------------------------------------------------------
+def box_room_voxels(lo=(-40, -30, -2), hi=(40, 30, 20), pillar=True):
+    """Occupied voxel list (i, j, k) of a box room: floor, ceiling, four walls, optionally a pillar."""
+    occ = []
+    for i in range(lo[0], hi[0] + 1):
+        for j in range(lo[1], hi[1] + 1):
+            occ.append((i, j, lo[2]))
+            occ.append((i, j, hi[2]))
+    for k in range(lo[2], hi[2] + 1):
+        for i in range(lo[0], hi[0] + 1):
+            occ.append((i, lo[1], k))
+            occ.append((i, hi[1], k))
+        for j in range(lo[1], hi[1] + 1):
+            occ.append((lo[0], j, k))
+            occ.append((hi[0], j, k))
+        if pillar:
+            for i in range(8, 12):
+                for j in range(-3, 1):
+                    occ.append((i, j, k))
+    return np.unique(np.array(occ, dtype=np.int32), axis=0)
+
+
+def sphere_cloud(rows, cols, pose_xyz, occupied, resolution, max_range=10.0, seed=3, noise=0.01):
+    """rows x cols spherical-grid cloud in the SCANNER frame: each ray is marched to the first
+    occupied voxel of `occupied` (input generation only)."""
+    rng = np.random.default_rng(seed)
+    occ = {tuple(v) for v in occupied.tolist()}
+    el = np.linspace(-0.4, 0.4, rows)
+    az = np.linspace(-np.pi, np.pi, cols, endpoint=False)
+    pts = []
+    step = resolution * 0.5
+    for e in el:
+        for a in az:
+            d = np.array([np.cos(e) * np.cos(a), np.cos(e) * np.sin(a), np.sin(e)])
+            r = step
+            hit = None
+            while r < max_range:
+                p = np.asarray(pose_xyz) + r * d
+                if tuple(np.floor(p / resolution + 0.5).astype(int)) in occ:
+                    hit = r
+                    break
+                r += step
+            if hit is not None:
+                pts.append(d * (hit + rng.normal(0, noise)))
+    return np.asarray(pts, dtype=np.float32)
