@@ -147,3 +147,50 @@ def sphere_cloud(rows, cols, pose_xyz, occupied, resolution, max_range=10.0, see
             if hit is not None:
                 pts.append(d * (hit + rng.normal(0, noise)))
     return np.asarray(pts, dtype=np.float32)
+
+
+def box_room_lut(resolution=0.05, max_dist=0.3, lo=(-40, -30, -2), hi=(40, 30, 20), pad=3):
+    """OctoMap-style two-level uint8 distance LUT of the box room, built with an exact Euclidean
+    distance transform (bench input only; the reference builds its LUT with a FIFO brushfire from
+    an octree, which is outside this engine's scope).  Returns (pose_indices, distance_ratios,
+    min_cells, max_cells) in the layout of octomap.cpp:315-355: column 0 is the shared all-255
+    column, every (x, y) column that holds a value < 255 gets its own run of num_z bytes."""
+    from scipy import ndimage
+    occ = box_room_voxels(lo, hi)
+    mn = occ.min(axis=0) - pad
+    mx = occ.max(axis=0) + pad
+    shape = tuple((mx - mn + 1).tolist())  # (x, y, z)
+    grid = np.ones(shape, dtype=bool)
+    grid[tuple((occ - mn).T)] = False
+    d = ndimage.distance_transform_edt(grid) * resolution
+    ratio = np.floor(np.minimum(d, max_dist) / max_dist * 255).astype(np.uint8)
+    w, h, nz = shape
+    pose_indices = np.zeros(w * h, dtype=np.uint32)
+    cols = [np.full(nz, 255, dtype=np.uint8)]
+    nxt = nz
+    for j in range(h):
+        for i in range(w):
+            col = ratio[i, j, :]
+            if (col < 255).any():
+                pose_indices[j * w + i] = nxt
+                cols.append(col)
+                nxt += nz
+    return pose_indices, np.concatenate(cols), mn.astype(np.int32), mx.astype(np.int32)
+
+
+def grid_cloud(rows=64, cols=1024, origin=(0.3, 0.2, 0.6), room_lo=(-2.0, -1.5, -0.1), room_hi=(2.0, 1.5, 1.0),
+               seed=7, noise=0.01):
+    """rows x cols spherical-grid cloud (scanner frame, scanner at `origin` with zero rotation) of
+    the axis-aligned box room, by analytic ray / box intersection."""
+    rng = np.random.default_rng(seed)
+    el = np.linspace(-0.5, 0.5, rows)[:, None]
+    az = np.linspace(-np.pi, np.pi, cols, endpoint=False)[None, :]
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)], axis=-1)
+    o = np.asarray(origin)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_lo = (np.asarray(room_lo) - o) / d
+        t_hi = (np.asarray(room_hi) - o) / d
+    t = np.where(d > 0, t_hi, t_lo)
+    t = np.where(np.isfinite(t) & (t > 0), t, np.inf).min(axis=-1)
+    pts = d * (t + rng.normal(0, noise, t.shape))[..., None]
+    return pts.reshape(-1, 3).astype(np.float32)

@@ -29,13 +29,24 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def algorithmic_bytes(model, n, beams, mean_cells=None):
-    """LF family 4 B/eval + 40 B/particle + 16 B/beam; beam model C x 1 B/eval."""
+    """SURVEY.md 8(d): LF family 4 B/eval + 40 B/particle + 16 B/beam; beam model C x 1 B/eval;
+    3-D 5 B/eval + 12 B/point + 40 B/particle."""
+    if model == "cloud3d":
+        return 5.0 * n * beams + 12.0 * beams + 40.0 * n
     per_eval = 4.0 if model != "beam" else float(mean_cells or 0.0)
     return per_eval * n * beams + 40.0 * n + 16.0 * beams
 
 
 def build_workload(args, rank):
     from badger_amcl_amd import synth
+    if args.model == "cloud3d":
+        # BASELINE.json configs[4]: 3-D likelihood field, 64 x 1024-point cloud
+        pi, dr, mn, mx = synth.box_room_lut()
+        pts = synth.grid_cloud(64, 1024)
+        n = args.particles
+        samples = synth.converged_cloud(n, np.array([0.0, 0.0, 0.0]), seed=42 + rank, sigma=(0.15, 0.15, 0.05))
+        return dict(lut3=(pi, dr, mn, mx), points=pts, samples=samples, n=n, beams=pts.shape[0],
+                    tf_xyz=(0.3, 0.2, 0.6), tf_quat=(0.0, 0.0, 0.0, 1.0))
     size, beams, n = args.map_size, args.beams, args.particles
     cells, origin = synth.make_map(size)
     pose = synth.true_pose(size)
@@ -52,6 +63,20 @@ def setup_engine(args, wl, device):
     import badger_amcl_amd as bpf
     from badger_amcl_amd import synth
     e = bpf.Engine(device)
+    if args.model == "cloud3d":
+        pi, dr, mn, mx = wl["lut3"]
+        m = bpf.OctoMap(e, 0.05)
+        m.setDistancesLUT(pi, dr, mn, mx, 0.3)
+        sc = bpf.PointCloudScanner(e)
+        sc.init(wl["beams"], m)
+        sc.setPointCloudModel(0.5, 0.05, 0.1)
+        sc.setMapFactors(*synth.MAP_FACTORS)
+        sc.setPointCloudScannerToFootprintTF(wl["tf_xyz"], wl["tf_quat"])
+        pf = bpf.ParticleFilter(e, 100, wl["n"] * wl.get("world", 1), 0.0, 0.0, 85.0)
+        pf.srand48(42)
+        pf.initWithSamples(wl["samples"])
+        pf.snapshot()
+        return e, m, sc, pf, bpf.PointCloudData(wl["points"]), None
     m = bpf.OccupancyMap(e, 0.05)
     m.setCells(wl["cells"])
     m.setOrigin(wl["origin"])
@@ -87,6 +112,22 @@ def cpu_baseline(args, wl, lut, budget_s):
     same workload, as many whole steps as fit the budget (at least one)."""
     from badger_amcl_amd import synth
     from oracle import pyoracle as orc
+    if args.model == "cloud3d":
+        pi, dr, mn, mx = wl["lut3"]
+        olut = orc.OctoMapLUT(mn, mx, 0.05, 0.3, pi, dr)
+        op = orc.cloud(orc.CLOUD_MODEL, wl["beams"], wl["tf_xyz"], wl["tf_quat"], z_hit=0.5, z_rand=0.05,
+                       sigma_hit=0.1)
+        op.off_map_factor = synth.MAP_FACTORS[0]
+        n_cpu = max(100, int(budget_s * 1.5e7 / wl["beams"]))  # ~65 ns per evaluation
+        opf = orc.ParticleFilter(100, n_cpu, 0.0, 0.0, 85.0, seed=42)
+        opf.set_samples(wl["samples"][:n_cpu], leaf_count=0)
+        t0 = time.perf_counter()
+        opf.update_sensor(lambda s, conv: orc.cloud_apply(op, olut, s, wl["points"]))
+        out = opf.update_resample()
+        dt = time.perf_counter() - t0
+        return dict(value=float(n_cpu) * wl["beams"] / dt, unit="particle-beam evals/s", cores=1, kind="port",
+                    sample="1 step of %d particles x %d points (3-D cloud model), %.1f s, oracle gcc -O2 single "
+                           "thread; resampled to M=%d" % (n_cpu, wl["beams"], dt, out.sample_count)), None, opf
     omap = orc.OccupancyMap(wl["cells"], 0.05, wl["origin"], 2.0, lut)
     if args.model == "lf":
         p = orc.planar(orc.MODEL_LF, wl["beams"], scanner_pose=synth.SCANNER_POSE, **synth.LF_DEFAULTS)
@@ -123,14 +164,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="lf", choices=["lf", "gompertz", "beam"])
+    ap.add_argument("--model", default="lf", choices=["lf", "gompertz", "beam", "cloud3d"])
     ap.add_argument("--cloud", default="converged", choices=["converged", "spread"])
     ap.add_argument("--resampler", default="multinomial", choices=["multinomial", "systematic"])
-    ap.add_argument("--particles", type=int, default=100000, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=None,
+                    help="particles per GPU (default 100000; 200000 for cloud3d)")
     ap.add_argument("--beams", type=int, default=1081)
     ap.add_argument("--map-size", type=int, default=2000)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
+    if args.particles is None:
+        args.particles = 200000 if args.model == "cloud3d" else 100000
 
     # Native libraries (RCCL prints a version banner) write to fd 1; keep the real stdout for the
     # one JSON line and send everything else to stderr.
@@ -237,8 +281,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D likelihood-field, 100k particles, 1081 beams, 2000x2000 map"
                        if (args.model, args.particles, args.beams, args.map_size) == ("lf", 100000, 1081, 2000)
-                       else "2D %s, %d particles/GPU, %d beams, %dx%d map" % (args.model, args.particles, args.beams,
-                                                                             args.map_size, args.map_size),
+                       else ("3D (octomap) likelihood-field, %d particles/GPU, 64x1024-point cloud" % args.particles
+                             if args.model == "cloud3d" else
+                             "2D %s, %d particles/GPU, %d beams, %dx%d map" % (args.model, args.particles, args.beams,
+                                                                               args.map_size, args.map_size)),
                        "cloud": args.cloud, "resampler": args.resampler, "particles_per_gpu": wl["n"],
                        "particles_total": n_total, "resampled_to": int(st.sample_count),
                        "kld_leaf_count": int(st.leaf_count), "parallelism": "particle-shard x%d" % world},
