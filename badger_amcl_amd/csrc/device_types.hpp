@@ -61,6 +61,7 @@ struct FieldScoreArgs
   int model;
   GompertzDev g;
   int n_valid;               // beams that count towards the Gompertz mean
+  double* block_partials;    // per-block sum of the updated weights (nullable)
   // prob model, counting pass
   int* obs_count;            // per staged beam: particles whose end point is near an obstacle
   int skip_level;            // levels below this index are "z < beam_skip_distance"

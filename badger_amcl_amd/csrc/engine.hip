@@ -190,7 +190,9 @@ struct bpf_engine
   bool count_cells = false;
   KdHistogram hist;
   SeenKeys seen;
-  DevBuf<double> d_cdf, d_partials, d_targets;
+  DevBuf<double> d_cdf, d_partials, d_targets, d_block_partials, d_tile_sums;
+  int fused_partials = 0;     // > 0: the last scoring launch left that many per-block weight partials
+  int tile_sums_n = -1;       // >= 0: d_tile_sums holds the 2048-tile sums of the current weights for that n
   DevBuf<FilterScalars> d_scalars;
   DevBuf<int> d_keys, d_src_index, d_flags;  // d_flags[0] miss, [1] converged count
   DevBuf<double4> d_aos;
@@ -504,7 +506,7 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
 }
 
 int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldScan& fs, int* obs_count,
-                 int skip_level)
+                 int skip_level, bool want_partials = false)
 {
   FieldScoreArgs A{};
   A.p = p;
@@ -532,6 +534,13 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1024));
   per_cu = std::max(per_cu, 1);
   const int grid = std::max(1, std::min(blocks_for(n_groups, 4), e->n_cu * per_cu));
+  A.block_partials = nullptr;
+  if (want_partials && !count_only)
+  {
+    HIPCHK(e, e->d_block_partials.reserve((size_t)grid));
+    A.block_partials = e->d_block_partials.p;
+    e->fused_partials = grid;
+  }
   ProfScope ps(e, BPF_K_SCORE);
   if (count_only)
     hipLaunchKernelGGL((k_score_field<true, false>), dim3(grid), dim3(256), lds, e->stream, A);
@@ -571,9 +580,11 @@ int ensure_scalars(bpf_engine* e)
 // Scores `n` particles of `p` with the configured planar model (+ recalcWeight).  Leaves the
 // weights un-normalised.  set_converged feeds the prob model's beam-skip switch.
 int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const double* ranges,
-                 const double* angles, int rc, double range_max, bool* forced_zero)
+                 const double* angles, int rc, double range_max, bool* forced_zero, bool want_partials = false)
 {
   *forced_zero = false;
+  e->fused_partials = 0;
+  e->tile_sums_n = -1;
   if (!e->have_map)
     return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
   if (!e->have_lut)
@@ -661,7 +672,7 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
   const bool beamskip = pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && pm.do_beamskip && set_converged;
   if (!beamskip)
   {
-    rcode = launch_field(e, p, n, s, fs, nullptr, 0);
+    rcode = launch_field(e, p, n, s, fs, nullptr, 0, want_partials);
     if (rcode != BPF_OK)
       return rcode;
     return release_slot(e, s);
@@ -756,14 +767,25 @@ int build_cdf(bpf_engine* e, const double* w, int n)
   if (e->cdf_serial)
   {
     hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, e->stream, w, n, e->d_cdf.p);
+    HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
   }
   else
   {
     const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
-    HIPCHK(e, e->d_partials.reserve((size_t)nb));
-    hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, e->d_partials.p);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_partials.p, nb);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, e->d_partials.p, e->d_cdf.p);
+    double* tiles;
+    if (e->tile_sums_n == n && w == e->sets[e->cur].w.p)
+    {
+      tiles = e->d_tile_sums.p;  // left behind by k_normalize_fused; consumed (scanned in place) here
+      e->tile_sums_n = -1;
+    }
+    else
+    {
+      HIPCHK(e, e->d_partials.reserve((size_t)nb));
+      tiles = e->d_partials.p;
+      hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles);
+    }
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, tiles, nb, e->d_flags.p);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, e->d_cdf.p);
   }
   HIPCHK(e, hipGetLastError());
   return BPF_OK;
@@ -799,7 +821,6 @@ int resample_multinomial(bpf_engine* e)
   HIPCHK(e, e->d_keys.reserve((size_t)maxs * 3));
   HIPCHK(e, e->d_src_index.reserve((size_t)maxs));
   HIPCHK(e, e->h_keys.reserve((size_t)maxs * 3));
-  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
   e->hist.clear();
   e->seen.reset((size_t)std::min(maxs, 1 << 20));
   int m0 = 0, stop = -1;
@@ -875,7 +896,6 @@ int resample_systematic(bpf_engine* e)
   HIPCHK(e, e->d_keys.reserve((size_t)e->max_samples * 3));
   HIPCHK(e, e->d_src_index.reserve((size_t)e->max_samples));
   HIPCHK(e, e->h_keys.reserve((size_t)e->max_samples * 3));
-  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
   SystematicArgs A{};
   A.src = a.dev();
   A.n_src = n;
@@ -973,6 +993,7 @@ void bpf_destroy(bpf_engine* e)
   e->d_cloud_partials.release(); e->d_cloud_table.release(); e->h_points.release(); e->h_cloud_table.release();
   e->sets[0].release(); e->sets[1].release(); e->scratch.release(); e->snap.release();
   e->d_cdf.release(); e->d_partials.release(); e->d_targets.release(); e->d_scalars.release();
+  e->d_block_partials.release(); e->d_tile_sums.release();
   e->d_keys.release(); e->d_src_index.release(); e->d_flags.release(); e->d_aos.release();
   e->h_keys.release(); e->h_flags.release(); e->h_scalars.release(); e->h_aos.release();
   if (e->own_stream)
@@ -1337,6 +1358,7 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
   if (rc != BPF_OK)
     return rc;
   e->sample_count = sample_count;
+  e->tile_sums_n = -1;
   // initWith*: w_slow_ = w_fast_ = 0, converged = false (particle_filter.cpp:127,157,164-168)
   HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
   e->converged = 0;
@@ -1408,15 +1430,14 @@ int bpf_pf_restore(bpf_engine* e)
   if (!e || !e->have_pf || e->snap_count <= 0)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
-  const size_t n = (size_t)e->snap_count;
-  SampleSet& s = e->sets[e->cur];
-  HIPCHK(e, hipMemcpyAsync(s.x.p, e->snap.x.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-  HIPCHK(e, hipMemcpyAsync(s.y.p, e->snap.y.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-  HIPCHK(e, hipMemcpyAsync(s.th.p, e->snap.th.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-  HIPCHK(e, hipMemcpyAsync(s.w.p, e->snap.w.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  const int n = e->snap_count;
+  hipLaunchKernelGGL(k_copy4, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->sets[e->cur].dev(),
+                     e->snap.dev(), n);
+  HIPCHK(e, hipGetLastError());
   e->sample_count = e->snap_count;
   e->leaf_count = e->snap_leaf;
   e->bin_count = e->snap_bins;
+  e->tile_sums_n = -1;
   return BPF_OK;
 }
 
@@ -1424,6 +1445,7 @@ int bpf_pf_fill_weights(bpf_engine* e, double weight)
 {
   if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
+  e->tile_sums_n = -1;
   HIPCHK(e, hipSetDevice(e->device));
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(e->sample_count, 256)), dim3(256), 0, e->stream,
                      e->sets[e->cur].w.p, weight, e->sample_count);
@@ -1450,18 +1472,33 @@ int bpf_pf_update_sensor_planar(bpf_engine* e, const double* ranges, const doubl
   SampleSet& s = e->sets[e->cur];
   const int n = e->sample_count;
   bool forced_zero = false;
-  int rc = score_planar(e, s.dev(), n, e->converged, ranges, angles, range_count, range_max, &forced_zero);
+  int rc = score_planar(e, s.dev(), n, e->converged, ranges, angles, range_count, range_max, &forced_zero, true);
   if (rc != BPF_OK)
     return rc;
-  rc = sum_into_slot(e, s.w.p, n, 0, 1, n);
-  if (rc != BPF_OK)
-    return rc;
+  if (e->fused_partials > 0)
   {
+    // the scoring kernel left per-block weight partials: one launch folds them, normalises, updates the
+    // running averages and leaves the tile sums for the CDF
+    const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+    HIPCHK(e, e->d_tile_sums.reserve((size_t)nb));
+    ProfScope ps(e, BPF_K_NORMALIZE);
+    hipLaunchKernelGGL(k_normalize_fused, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
+                       e->d_block_partials.p, e->fused_partials, e->d_scalars.p, e->alpha_slow, e->alpha_fast,
+                       e->d_tile_sums.p);
+    HIPCHK(e, hipGetLastError());
+    e->tile_sums_n = n;
+    e->fused_partials = 0;
+  }
+  else
+  {
+    rc = sum_into_slot(e, s.w.p, n, 0, 1, n);
+    if (rc != BPF_OK)
+      return rc;
     ProfScope ps(e, BPF_K_NORMALIZE);
     hipLaunchKernelGGL(k_normalize, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.w.p, n, e->d_scalars.p, 0,
                        0.0, n);
+    HIPCHK(e, hipGetLastError());
   }
-  HIPCHK(e, hipGetLastError());
   e->last_status = BPF_OK;
   return BPF_OK;
 }
@@ -1501,18 +1538,32 @@ int bpf_pf_update_resample(bpf_engine* e)
     return rc;
   const int M = e->sample_count;
   SampleSet& b = e->sets[e->cur ^ 1];
-  {
-    ProfScope ps(e, BPF_K_FINALIZE);
-    // weight 1.0 each, total = M, then weight /= total (particle_filter.cpp:409,458-462)
-    hipLaunchKernelGGL(k_fill, dim3(blocks_for(M, 256)), dim3(256), 0, e->stream, b.w.p, 1.0 / (double)M, M);
-  }
-  HIPCHK(e, hipGetLastError());
+  e->tile_sums_n = -1;
   e->cur ^= 1;
   e->leaf_count = e->hist.leaf_count();
   e->bin_count = e->hist.bin_count();
-  rc = launch_converged(e);
-  if (rc != BPF_OK)
-    return rc;
+  if (M <= 8192)
+  {
+    // small resampled set: weights 1/M and updateConverged in one single-block launch
+    ProfScope ps(e, BPF_K_FINALIZE);
+    hipLaunchKernelGGL(k_resample_tail_small, dim3(1), dim3(1024), 0, e->stream, b.x.p, b.y.p, b.w.p, M,
+                       e->dist_threshold, e->d_scalars.p, e->d_flags.p + 1);
+    HIPCHK(e, hipGetLastError());
+    e->converged_pending = true;
+    e->conv_n = M;
+  }
+  else
+  {
+    {
+      ProfScope ps(e, BPF_K_FINALIZE);
+      // weight 1.0 each, total = M, then weight /= total (particle_filter.cpp:409,458-462)
+      hipLaunchKernelGGL(k_fill, dim3(blocks_for(M, 256)), dim3(256), 0, e->stream, b.w.p, 1.0 / (double)M, M);
+    }
+    HIPCHK(e, hipGetLastError());
+    rc = launch_converged(e);
+    if (rc != BPF_OK)
+      return rc;
+  }
   // miss flag was copied? read it with the next fetch; report asynchronously via last_status
   e->last_status = BPF_OK;
   return BPF_OK;
@@ -1770,6 +1821,7 @@ int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_poi
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
   const int n = e->sample_count;
+  e->tile_sums_n = -1;
   int rc = score_cloud(e, s.dev(), n, points_xyz, n_points);
   if (rc != BPF_OK)
     return rc;
@@ -1825,6 +1877,7 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
   const int n = e->sample_count;
+  e->tile_sums_n = -1;
   ProfScope ps(e, BPF_K_NORMALIZE);
   hipLaunchKernelGGL(k_normalize_gathered, dim3(std::max(1, blocks_for(n, 256))), dim3(256), 0, e->stream, s.w.p, n,
                      static_cast<const double*>(totals_dev), world, global_sample_count, e->d_scalars.p,
@@ -1894,6 +1947,7 @@ int bpf_shard_adopt_dev(bpf_engine* e, const void* x_dev, const void* y_dev, con
   e->sample_count = count;
   e->leaf_count = leaf_count;
   e->bin_count = bin_count;
+  e->tile_sums_n = -1;
   return BPF_OK;
 }
 

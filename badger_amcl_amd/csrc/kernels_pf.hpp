@@ -133,6 +133,123 @@ __global__ void k_normalize(double* __restrict__ w, int n, const FilterScalars* 
     w[i] = 1.0 / global_n;
 }
 
+// Fused tail of ParticleFilter::updateSensor (particle_filter.cpp:237-266): every block folds the
+// scoring kernel's per-block weight partials into the total (same fixed tree in every block, so
+// all blocks agree bit for bit), normalises its 2048-element tile, and leaves the tile's sum of
+// normalised weights for the CDF scan.  Block 0 records the total and updates w_slow / w_fast.
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_fused(double* __restrict__ w, int n,
+                                                                  const double* __restrict__ block_partials,
+                                                                  int n_partials, FilterScalars* sc,
+                                                                  double alpha_slow, double alpha_fast,
+                                                                  double* __restrict__ tile_sums)
+{
+  __shared__ double s_wave[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += BPF_RED_BLOCK)
+    acc += block_partials[i];
+  const double total = block_sum_256(acc, s_wave);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    sc->v[0] = total;
+    sc->v[6] = total;
+    if (total > 0.0)
+    {
+      const double w_avg = total / n;
+      double ws = sc->v[1], wf = sc->v[2];
+      if (ws == 0.0)
+        ws = w_avg;
+      else
+        ws += alpha_slow * (w_avg - ws);
+      if (wf == 0.0)
+        wf = w_avg;
+      else
+        wf += alpha_fast * (w_avg - wf);
+      sc->v[1] = ws;
+      sc->v[2] = wf;
+    }
+  }
+  const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
+  const double uniform = 1.0 / n;
+  double tsum = 0.0;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+    if (base + k < (size_t)n)
+    {
+      const double v = (total > 0.0) ? w[base + k] / total : uniform;
+      w[base + k] = v;
+      tsum += v;
+    }
+  const double tile = block_sum_256(tsum, s_wave);
+  if (threadIdx.x == 0)
+    tile_sums[blockIdx.x] = tile;
+}
+
+// one launch instead of four device-to-device copies
+__global__ void k_copy4(ParticlesDev dst, ParticlesDev src, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  dst.x[i] = src.x[i];
+  dst.y[i] = src.y[i];
+  dst.th[i] = src.th[i];
+  dst.w[i] = src.w[i];
+}
+
+// Tail of updateResample for a small resampled set (one block): weights 1/M
+// (particle_filter.cpp:409,458-462) and updateConverged (:170-220).
+__global__ __launch_bounds__(1024) void k_resample_tail_small(const double* __restrict__ x,
+                                                             const double* __restrict__ y,
+                                                             double* __restrict__ w, int n, double thr,
+                                                             FilterScalars* sc, int* __restrict__ count_out)
+{
+  __shared__ double s_x[16], s_y[16];
+  __shared__ int s_c[16];
+  const double weight = 1.0 / (double)n;
+  double ax = 0.0, ay = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024)
+  {
+    w[i] = weight;
+    ax += x[i];
+    ay += y[i];
+  }
+  ax = wave_sum(ax);
+  ay = wave_sum(ay);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+    s_x[wave] = ax;
+    s_y[wave] = ay;
+  }
+  __syncthreads();
+  double sx = 0.0, sy = 0.0;
+  for (int k = 0; k < 16; ++k)
+  {
+    sx += s_x[k];
+    sy += s_y[k];
+  }
+  const double mx = sx / n, my = sy / n;
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 1024)
+    if (fabs(x[i] - mx) <= thr && fabs(y[i] - my) <= thr)
+      c++;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    c += __shfl_xor(c, off, 64);
+  if (lane == 0)
+    s_c[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    int tot = 0;
+    for (int k = 0; k < 16; ++k)
+      tot += s_c[k];
+    *count_out = tot;
+    sc->v[3] = sx;
+    sc->v[4] = sy;
+  }
+}
+
 // Sharded variant: the global total is the rank-ordered sum of the gathered per-shard totals;
 // thread 0 of block 0 also applies the running-average update with the global numbers.
 __global__ void k_normalize_gathered(double* __restrict__ w, int n, const double* __restrict__ totals, int world,
@@ -187,13 +304,18 @@ __device__ __forceinline__ double wave_incl_scan(double v)
   return v;
 }
 
-__global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_tile_offsets(double* __restrict__ partials, int n_partials)
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_tile_offsets(double* __restrict__ partials, int n_partials,
+                                                                    int* __restrict__ zero_word)
 {
   // exclusive scan of the tile sums in place, serial per 256-chunk carry; n_partials is small
   __shared__ double s_wave[4];
   __shared__ double s_carry;
   if (threadIdx.x == 0)
+  {
     s_carry = 0.0;
+    if (zero_word != nullptr)
+      *zero_word = 0;  // the CDF-miss flag of the draw kernels that follow
+  }
   __syncthreads();
   for (int base = 0; base < n_partials; base += BPF_RED_BLOCK)
   {

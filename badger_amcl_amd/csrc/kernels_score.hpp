@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
   const double* table = TABLE_IN_LDS ? s_table : A.table;
   const char* __restrict__ tiles = reinterpret_cast<const char*>(M.lut_tiles);
   const int n_beams = A.n_beams;
+  double wsum = 0.0;  // this lane's share of the block's weight total
 
   for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4)
   {
@@ -254,7 +255,19 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
       double w = A.p.w[q] * p;
       w *= recalc_factor(M, px, py, A.off_map_factor, A.non_free_factor, A.non_free_radius);
       A.p.w[q] = w;
+      wsum += w;
     }
+  }
+  if (!COUNT_ONLY && A.block_partials != nullptr)
+  {
+    // fixed shape: lanes -> wave (xor tree), waves 0..3 in order: reproducible for a given grid
+    __shared__ double s_part[4];
+    const double ws = wave_sum(wsum);
+    if (lane == 0)
+      s_part[wave] = ws;
+    __syncthreads();
+    if (tid == 0)
+      A.block_partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
   }
 }
 
