@@ -147,6 +147,21 @@ struct bpf_engine
   PlanarModel pm;
   ScanSlot ring[kRing];
   int ring_next = 0;
+  // host-side caches of scan staging: cos/sin of the bearings (a sensor's bearings are the same
+  // arithmetic sequence scan after scan, node_2d.cpp:559) and the per-level term table (depends
+  // only on the model parameters, range_max and the map)
+  std::vector<double> trig_angles, trig_cos, trig_sin;
+  std::vector<double> term_table;
+  struct TermKey
+  {
+    int model = -1, map_version = -1;
+    double z_hit = 0, z_rand = 0, sigma = 0, range_max = 0;
+    bool operator==(const TermKey& o) const
+    {
+      return model == o.model && map_version == o.map_version && z_hit == o.z_hit && z_rand == o.z_rand &&
+             sigma == o.sigma && range_max == o.range_max;
+    }
+  } term_key;
   DevBuf<int> d_obs_count;
   DevBuf<unsigned long long> d_cells_walked;
 
@@ -206,6 +221,7 @@ struct bpf_engine
 
   // ---- profiling
   bool profiling = false;
+  bool profile_all = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
   std::vector<int> ev_class;
   size_t ev_used = 0;
@@ -241,7 +257,7 @@ struct ProfScope
   int idx = -1;
   ProfScope(bpf_engine* eng, int klass) : e(eng)
   {
-    if (!e->profiling || e->ev_used >= e->ev_start.size())
+    if (!e->profiling || e->ev_used >= e->ev_start.size() || (klass != BPF_K_SCORE && !e->profile_all))
       return;
     idx = (int)e->ev_used++;
     e->ev_class[idx] = klass;
@@ -426,6 +442,17 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
     step = 1;
   const int K = e->map.n_levels;
   fs->table_len = K + 1;
+  if ((int)e->trig_angles.size() != rc || std::memcmp(e->trig_angles.data(), angles, (size_t)rc * sizeof(double)) != 0)
+  {
+    e->trig_angles.assign(angles, angles + rc);
+    e->trig_cos.resize(rc);
+    e->trig_sin.resize(rc);
+    for (int i = 0; i < rc; ++i)
+    {
+      e->trig_cos[i] = std::cos(angles[i]);
+      e->trig_sin[i] = std::sin(angles[i]);
+    }
+  }
   std::vector<double2> beams;
   beams.reserve(rc / step + 1);
   fs->slot_of.clear();
@@ -443,8 +470,8 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
     if (keep_slot && !(slot < (int)keep_slot->size() && (*keep_slot)[slot]))
       continue;
     double2 b;
-    b.x = (r * std::cos(angles[i])) / res;
-    b.y = (r * std::sin(angles[i])) / res;
+    b.x = (r * e->trig_cos[i]) / res;
+    b.y = (r * e->trig_sin[i]) / res;
     // a non-finite or absurdly long beam ends off the map in the reference ((int) of a NaN or
     // huge double is INT_MIN on x86); (1e18, 0) rotates to an off-map end point for every pose
     if (!(std::fabs(b.x) < 1e15 && std::fabs(b.y) < 1e15))
@@ -468,9 +495,17 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
     return rcode;
   std::memcpy(s->host.p + fs->beams_off, beams.data(), beams.size() * sizeof(double2));
   double* table = reinterpret_cast<double*>(s->host.p + fs->table_off);
+  bpf_engine::TermKey key;
+  key.model = pm.model;
+  key.map_version = e->map_version;
+  key.z_hit = pm.z_hit;
+  key.z_rand = pm.z_rand;
+  key.sigma = pm.sigma_hit;
+  key.range_max = range_max;
+  const bool table_cached = key == e->term_key && (int)e->term_table.size() == K + 1;
   const double denom = 2 * pm.sigma_hit * pm.sigma_hit;
   const double rand_mult = 1.0 / range_max;
-  for (int k = 0; k <= K; ++k)
+  for (int k = 0; k <= K && !table_cached; ++k)
   {
     const bool off_map = (k == K);
     const double z = off_map ? e->map.max_dist : (double)e->h_levels[k];
@@ -499,6 +534,13 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
       pz += pm.z_rand * rand_mult;
       table[k] = std::log(pz);
     }
+  }
+  if (table_cached)
+    std::memcpy(table, e->term_table.data(), (size_t)(K + 1) * sizeof(double));
+  else
+  {
+    e->term_table.assign(table, table + K + 1);
+    e->term_key = key;
   }
   HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs->bytes, hipMemcpyHostToDevice, e->stream));
   *slot_out = s;
@@ -2084,6 +2126,7 @@ int bpf_profile_enable(bpf_engine* e, int on)
     }
   }
   e->profiling = on != 0;
+  e->profile_all = on >= 2;
   return BPF_OK;
 }
 

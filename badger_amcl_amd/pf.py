@@ -71,7 +71,8 @@ class Engine:
     def synchronize(self):
         self.check(self.lib.bpf_synchronize(self.h))
 
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=1):
+        """1 = time the scoring kernel only, 2 = every kernel class, 0 = off."""
         self.check(self.lib.bpf_profile_enable(self.h, int(on)))
 
     def profile_reset(self):

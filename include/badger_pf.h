@@ -266,7 +266,9 @@ typedef struct
   double ms[BPF_K_COUNT];          /* accumulated HIP-event time per kernel class */
   long long launches[BPF_K_COUNT];
 } bpf_profile;
-/* When on, every launch of the dominant kernel is bracketed by hipEvents on the engine stream. */
+/* on = 1: every launch of the dominant (scoring) kernel is bracketed by hipEvents on the engine
+ * stream (two event records per update); on = 2: every kernel class is (costs ~2 us of host time
+ * per event, so not for timed regions); 0: off. */
 int bpf_profile_enable(bpf_engine* e, int on);
 int bpf_profile_reset(bpf_engine* e);
 int bpf_profile_get(bpf_engine* e, bpf_profile* out);
