@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libbadger_pf_hip.so")
+SO = os.environ.get("BPF_LIB") or os.path.join(HERE, "libbadger_pf_hip.so")  # BPF_LIB: experiment builds
 
 BPF_K_COUNT = 8
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "bpf_profile_reset": (C.c_int, [_vp]),
     "bpf_profile_get": (C.c_int, [_vp, C.POINTER(Profile)]),
     "bpf_score_kernel_name": (C.c_char_p, [_vp]),
+    "bpf_get_window_plan": (C.c_int, [_vp, _ip, _ip, _ip]),
 }
 
 _lib = None

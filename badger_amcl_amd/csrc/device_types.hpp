@@ -11,9 +11,10 @@ namespace bpf
 //    (one tile = 128 B = one cache line), so that beam end points that are close in
 //    EITHER axis share lines.  levels[idx] is the float distance of the reference's
 //    distances_lut_ (include/amcl/map/occupancy_map.h:99).  The tiled image carries a
-//    border of one tile (8 cells) on every side filled with the off-map level K: an end
-//    point is clamped into [7, size+8] per axis and looked up without any bounds test.
-//    Element offset of padded cell (u, v):  (v&~7)*(8*ltx-8) + 8*v + (u&~7)*7 + u.
+//    border of one cell on every side filled with the off-map level K: an end point is
+//    clamped into [0, size+1] per axis (one unsigned min) and looked up without a bounds test.
+//    The stored value is level*8, the byte offset of the level's term in the per-scan table.
+//    Byte offset of padded cell (u, v):  (v&~7)*(16*ltx-16) + 16*v + (u&~7)*14 + 2*u.
 //  * notfree_tiles: one bit per cell (1 = not CELL_FREE), 8x8 cells per 64-bit word;
 //    bits of cells beyond the map edge inside a partial tile are 1.
 //  * cells8: the tri-state grid narrowed to int8, row-major i + j*size_x.
@@ -25,7 +26,7 @@ struct MapDev
   const float* levels;
   int size_x, size_y;
   int tiles_x, tiles_y;   // tiles of the un-padded grid (notfree_tiles)
-  int ltx, lty;           // tiles per row / column of the padded LUT image (tiles + 2)
+  int ltx, lty;           // tiles per row / column of the padded LUT image
   int half_x, half_y;     // size/2, the centre offset of convertWorldToMap
   int n_levels;        // K; index K is reserved for "off map"
   double origin_x, origin_y;  // float origin promoted to double (occupancy_map.cpp:96-97)
@@ -51,6 +52,7 @@ struct FieldScoreArgs
 {
   ParticlesDev p;
   int n;
+  const double4* prep;   // per particle (Qx, Qy, cos, sin) from k_field_prep
   const double2* beams;  // per valid beam: r*cos(bearing)/res, r*sin(bearing)/res
   int n_beams;
   const double* table;   // per LUT level (+1 off-map entry): the per-beam term
@@ -58,10 +60,13 @@ struct FieldScoreArgs
   MapDev map;
   double sp_x, sp_y, sp_th;  // scanner pose in the robot frame
   double off_map_factor, non_free_factor, non_free_radius;
+  double extra_term;         // sum of the terms of beams that are off the map for every pose
+  int per_wave;              // particles owned by each wave (static partition)
   int model;
   GompertzDev g;
   int n_valid;               // beams that count towards the Gompertz mean
   double* block_partials;    // per-block sum of the updated weights (nullable)
+  const int* skip_if_set;    // nullable: when *skip_if_set != 0 the window path does this update
   // prob model, counting pass
   int* obs_count;            // per staged beam: particles whose end point is near an obstacle
   int skip_level;            // levels below this index are "z < beam_skip_distance"

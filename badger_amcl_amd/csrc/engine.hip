@@ -16,6 +16,7 @@
 #include "kernels_cloud.hpp"
 #include "kernels_pf.hpp"
 #include "kernels_score.hpp"
+#include "kernels_window.hpp"
 
 using namespace bpf;
 
@@ -163,6 +164,13 @@ struct bpf_engine
     }
   } term_key;
   DevBuf<int> d_obs_count;
+  // LDS-window scoring path
+  DevBuf<double4> d_prep;
+  DevBuf<double> d_prep_stats, d_chunk_partials;
+  DevBuf<WindowPlan> d_plan;
+  bool window_lds_attr_set = false;
+  bool window_enabled = false;  // measured: no gain on wide clouds; opt-in via BPF_OPT_WINDOW_PATH
+  bool last_used_window_path = false;
   DevBuf<unsigned long long> d_cells_walked;
 
   // ---- 3-D map + point-cloud scanner
@@ -257,7 +265,8 @@ struct ProfScope
   int idx = -1;
   ProfScope(bpf_engine* eng, int klass) : e(eng)
   {
-    if (!e->profiling || e->ev_used >= e->ev_start.size() || (klass != BPF_K_SCORE && !e->profile_all))
+    if (!e->profiling || e->ev_used >= e->ev_start.size() ||
+        (klass != BPF_K_SCORE && klass != BPF_K_SCORE_WINDOW && !e->profile_all))
       return;
     idx = (int)e->ev_used++;
     e->ev_class[idx] = klass;
@@ -322,8 +331,8 @@ int encode_lut(bpf_engine* e, const float* lut)
     if (seen.emplace(bits, 0).second)
     {
       levels.push_back(lut[i]);
-      if (levels.size() > 65535)
-        return e->fail(BPF_ERR_LUT_LEVELS, "distance LUT holds more than 65535 distinct values");
+      if (levels.size() > 8190)
+        return e->fail(BPF_ERR_LUT_LEVELS, "distance LUT holds more than 8190 distinct values");
     }
   }
   std::sort(levels.begin(), levels.end());
@@ -333,9 +342,10 @@ int encode_lut(bpf_engine* e, const float* lut)
     std::memcpy(&bits, &levels[k], 4);
     seen[bits] = (int)k;
   }
-  // padded image: one tile of border all round, filled with the off-map level K
+  // padded image: a border cell all round, everything outside the map holds the off-map level K;
+  // entries are level*8 (byte offset of the level's term in the per-scan table)
   const int tx = e->map.ltx, ty = e->map.lty;
-  const uint16_t off_map_level = (uint16_t)levels.size();
+  const uint16_t off_map_level = (uint16_t)(levels.size() * 8);
   std::vector<uint16_t> tiles((size_t)tx * ty * 64, off_map_level);
   for (int j = 0; j < sy; ++j)
   {
@@ -350,8 +360,8 @@ int encode_lut(bpf_engine* e, const float* lut)
         prev_idx = seen[bits];
         prev_bits = bits;
       }
-      const int u = i + 8, v = j + 8;
-      tiles[((size_t)(v >> 3) * tx + (u >> 3)) * 64 + ((v & 7) << 3) + (u & 7)] = (uint16_t)prev_idx;
+      const int u = i + 1, v = j + 1;
+      tiles[((size_t)(v >> 3) * tx + (u >> 3)) * 64 + ((v & 7) << 3) + (u & 7)] = (uint16_t)(prev_idx * 8);
     }
   }
   HIPCHK(e, e->d_lut_tiles.reserve(tiles.size()));
@@ -421,6 +431,8 @@ struct FieldScan
 {
   int n_valid = 0;             // beams that pass the range_max / NaN tests
   int n_staged = 0;            // of those, the ones uploaded (all, or the kept ones of beam skipping)
+  int n_always_off = 0;        // valid beams too long / non-finite to stage: off the map for every pose
+  double off_map_term = 0.0;   // table[K]
   int n_slots = 0;             // beam_ind range of the prob model
   std::vector<int> slot_of;    // staged beam -> beam_ind
   size_t beams_off = 0, table_off = 0, bytes = 0;
@@ -457,6 +469,7 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
   beams.reserve(rc / step + 1);
   fs->slot_of.clear();
   fs->n_valid = 0;
+  fs->n_always_off = 0;
   int slot = 0;
   const double res = e->map.resolution;
   for (int i = 0; i < rc; i += step, ++slot)
@@ -472,12 +485,13 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
     double2 b;
     b.x = (r * e->trig_cos[i]) / res;
     b.y = (r * e->trig_sin[i]) / res;
-    // a non-finite or absurdly long beam ends off the map in the reference ((int) of a NaN or
-    // huge double is INT_MIN on x86); (1e18, 0) rotates to an off-map end point for every pose
-    if (!(std::fabs(b.x) < 1e15 && std::fabs(b.y) < 1e15))
+    // a non-finite or absurdly long beam (> 2^28 cells) ends off the map for every pose in the
+    // reference ((int) of a NaN or huge double is INT_MIN on x86): it is not staged, its constant
+    // off-map term is added in the epilogue instead
+    if (!(std::fabs(b.x) < 268435456.0 && std::fabs(b.y) < 268435456.0))
     {
-      b.x = 1e18;
-      b.y = 0.0;
+      ++fs->n_always_off;
+      continue;
     }
     beams.push_back(b);
     fs->slot_of.push_back(slot);
@@ -542,6 +556,7 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
     e->term_table.assign(table, table + K + 1);
     e->term_key = key;
   }
+  fs->off_map_term = table[K];
   HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs->bytes, hipMemcpyHostToDevice, e->stream));
   *slot_out = s;
   return BPF_OK;
@@ -569,19 +584,100 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   A.n_valid = fs.n_valid;
   A.obs_count = obs_count;
   A.skip_level = skip_level;
+  A.extra_term = 0.0;
+  for (int k = 0; k < fs.n_always_off; ++k)
+    A.extra_term += fs.off_map_term;
   const bool count_only = obs_count != nullptr;
   const bool table_lds = !count_only && fs.table_len <= kTableLdsMax;
-  const size_t lds = (size_t)fs.n_staged * sizeof(double2) + (table_lds ? (size_t)fs.table_len * sizeof(double) : 0);
-  const int n_groups = (n + 15) / 16;
-  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1024));
-  per_cu = std::max(per_cu, 1);
-  const int grid = std::max(1, std::min(blocks_for(n_groups, 4), e->n_cu * per_cu));
+  const size_t table_bytes = table_lds ? (((size_t)fs.table_len * sizeof(double) + 15) & ~(size_t)15) : 0;
+  const size_t lds = (size_t)fs.n_staged * sizeof(double2) + table_bytes;
+  // per-particle scanner pose / trig once per update (shared by both scoring forms)
+  const int prep_blocks = blocks_for(n, 256);
+  HIPCHK(e, e->d_prep.reserve((size_t)n));
+  HIPCHK(e, e->d_prep_stats.reserve((size_t)prep_blocks * kPrepStats));
+  {
+    ProfScope pa(e, BPF_K_SCORE_AUX);
+    hipLaunchKernelGGL(k_field_prep, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y, A.sp_th,
+                       e->d_prep.p, e->d_prep_stats.p);
+  }
+  A.prep = e->d_prep.p;
+  // One resident round: blocks per CU = what registers, LDS and the SGPR rule admit (the occupancy
+  // API can over-report by one block for SGPR-heavy kernels: MI355X_MICROARCH.md, residency).
+  int api_blocks = 0;
+  const void* kfn = count_only ? reinterpret_cast<const void*>(&k_score_field<true, false>)
+                               : (table_lds ? reinterpret_cast<const void*>(&k_score_field<false, true>)
+                                            : reinterpret_cast<const void*>(&k_score_field<false, false>));
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, kfn, 256, lds) != hipSuccess || api_blocks < 1)
+    api_blocks = 1;
+  const int per_cu = std::max(1, std::min(api_blocks, 6));
+  const int resident_waves = e->n_cu * per_cu * 4;
+  A.per_wave = std::max(1, blocks_for(n, resident_waves));
+  const int grid = std::max(1, blocks_for(blocks_for(n, A.per_wave), 4));
   A.block_partials = nullptr;
+  A.skip_if_set = nullptr;
+  e->last_used_window_path = false;
   if (want_partials && !count_only)
   {
     HIPCHK(e, e->d_block_partials.reserve((size_t)grid));
     A.block_partials = e->d_block_partials.p;
     e->fused_partials = grid;
+    // LDS-window path for big updates: the device decides (from the cloud's spread) whether the
+    // window kernels or k_score_field do the work; the other one returns immediately.
+    const int n_chunks = (fs.n_staged + 63) / 64;
+    const size_t win_lds = (size_t)kWinDim * kWinDim * sizeof(uint16_t) + ((size_t)fs.table_len + 1) * 8 + 64 * 16;
+    if (e->window_enabled && n >= 16384 && fs.n_staged >= 64 && n_chunks <= kMaxChunks && table_lds &&
+        fs.table_len <= 2047 && win_lds <= 160 * 1024)
+    {
+      HIPCHK(e, e->d_chunk_partials.reserve((size_t)n_chunks * n));
+      HIPCHK(e, e->d_plan.reserve(1));
+      if (!e->window_lds_attr_set)
+      {
+        HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_window),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e->window_lds_attr_set = true;
+      }
+      {
+        ProfScope pa(e, BPF_K_SCORE_AUX);
+        hipLaunchKernelGGL(k_field_windows, dim3(1), dim3(1024), 0, e->stream, e->d_prep_stats.p, prep_blocks,
+                           A.beams, fs.n_staged, e->map, e->d_plan.p);
+      }
+      WindowScoreArgs W{};
+      W.n = n;
+      W.prep = e->d_prep.p;
+      W.beams = A.beams;
+      W.n_beams = fs.n_staged;
+      W.table = A.table;
+      W.table_len = fs.table_len;
+      W.map = e->map;
+      W.plan = e->d_plan.p;
+      W.partials = e->d_chunk_partials.p;
+      W.slabs = std::max(1, e->n_cu / n_chunks);
+      {
+        ProfScope pw(e, BPF_K_SCORE_WINDOW);
+        hipLaunchKernelGGL(k_score_window, dim3(n_chunks, W.slabs), dim3(kWinThreads), win_lds, e->stream, W);
+      }
+      FieldFinishArgs F{};
+      F.p = p;
+      F.n = n;
+      F.partials = e->d_chunk_partials.p;
+      F.plan = e->d_plan.p;
+      F.map = e->map;
+      F.off_map_factor = A.off_map_factor;
+      F.non_free_factor = A.non_free_factor;
+      F.non_free_radius = A.non_free_radius;
+      F.model = A.model;
+      F.g = A.g;
+      F.n_valid = A.n_valid;
+      F.extra_term = A.extra_term;
+      F.block_partials = A.block_partials;
+      {
+        ProfScope pa(e, BPF_K_SCORE_AUX);
+        hipLaunchKernelGGL(k_field_finish, dim3(grid), dim3(256), 0, e->stream, F);
+      }
+      HIPCHK(e, hipGetLastError());
+      A.skip_if_set = &e->d_plan.p->use_window;
+      e->last_used_window_path = true;
+    }
   }
   ProfScope ps(e, BPF_K_SCORE);
   if (count_only)
@@ -1031,6 +1127,7 @@ void bpf_destroy(bpf_engine* e)
   e->d_lut_tiles.release(); e->d_notfree.release(); e->d_cells8.release(); e->d_levels.release();
   e->d_lut_f32.release(); e->d_edt_tmp.release(); e->d_obs_count.release();
   e->d_cells_walked.release();
+  e->d_prep.release(); e->d_prep_stats.release(); e->d_chunk_partials.release(); e->d_plan.release();
   e->d_pose_indices.release(); e->d_ratios.release(); e->d_affine.release(); e->d_points.release();
   e->d_cloud_partials.release(); e->d_cloud_table.release(); e->h_points.release(); e->h_cloud_table.release();
   e->sets[0].release(); e->sets[1].release(); e->scratch.release(); e->snap.release();
@@ -1096,8 +1193,8 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
   M.size_y = size_y;
   M.tiles_x = (size_x + 7) / 8;
   M.tiles_y = (size_y + 7) / 8;
-  M.ltx = (size_x + 8 + 8 + 7) / 8;  // cells -8 .. size+8 inclusive
-  M.lty = (size_y + 8 + 8 + 7) / 8;
+  M.ltx = (size_x + 2 + 7) / 8 + 1;  // padded cells 0 .. size+1, plus a spare tile column for 8-aligned windows
+  M.lty = (size_y + 2 + 7) / 8;
   if ((size_t)M.ltx * 16 >= (1u << 24) || (size_t)M.ltx * M.lty * 128 >= (1ull << 32))
     return e->fail(BPF_ERR_CAPACITY, "map too large for the 32-bit tiled LUT addressing");
   M.half_x = size_x / 2;
@@ -2086,6 +2183,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     return BPF_ERR_INVALID_ARGUMENT;
   if (option == BPF_OPT_CDF_SERIAL)
     e->cdf_serial = value != 0;
+  else if (option == BPF_OPT_WINDOW_PATH)
+    e->window_enabled = value != 0;
   else if (option == BPF_OPT_COUNT_CELLS)
     e->count_cells = value != 0;
   else
@@ -2164,6 +2263,30 @@ int bpf_profile_get(bpf_engine* e, bpf_profile* out)
   int rc = drain_events(e);
   *out = e->prof;
   return rc;
+}
+
+int bpf_get_window_plan(bpf_engine* e, int* used_window, int* chunks_covered, int* chunks_total)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  int uw = 0, cov = 0, tot = 0;
+  if (e->last_used_window_path && e->d_plan.p)
+  {
+    HIPCHK(e, hipSetDevice(e->device));
+    WindowPlan plan;
+    HIPCHK(e, hipMemcpyAsync(&plan, e->d_plan.p, sizeof(int) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    uw = plan.use_window;
+    cov = plan.covered;
+    tot = plan.n_chunks;
+  }
+  if (used_window)
+    *used_window = uw;
+  if (chunks_covered)
+    *chunks_covered = cov;
+  if (chunks_total)
+    *chunks_total = tot;
+  return BPF_OK;
 }
 
 const char* bpf_score_kernel_name(const bpf_engine* e)

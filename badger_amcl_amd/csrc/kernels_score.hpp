@@ -45,25 +45,26 @@ __device__ __forceinline__ int world_to_cell(double v, double origin, double res
   return (f == f) ? (int)f + half : -1;
 }
 
-constexpr int kLutPad = 8;  // border cells of the padded LUT image
+constexpr int kLutPad = 1;  // border cells (holding the off-map level) on each side of the LUT image
 
-// clamp(x, lo, hi); the bound is asserted so the compiler may fold max+min into v_med3_i32
-__device__ __forceinline__ int clamp_i32(int x, int lo, int hi)
+// Clamp a padded cell coordinate into [0, size + 1]: negative values wrap to huge unsigned numbers
+// and land on the far border, which holds the same off-map level as the near one.
+__device__ __forceinline__ unsigned clamp_cell(int c, int size)
 {
-  __builtin_assume(hi >= lo);
-  return min(max(x, lo), hi);
+  return min((unsigned)c, (unsigned)(size + kLutPad));
 }
 
 // byte offset of padded cell (u, v) in lut_tiles (see MapDev)
-__device__ __forceinline__ unsigned lut_byte_offset(const MapDev& m, int u, int v)
+__device__ __forceinline__ unsigned lut_byte_offset(const MapDev& m, unsigned u, unsigned v)
 {
-  const unsigned a = (unsigned)u & ~7u, b = (unsigned)v & ~7u;
-  const unsigned t = __umul24(a, 14u) + ((unsigned)u << 1);
+  const unsigned a = u & ~7u, b = v & ~7u;
+  const unsigned t = __umul24(a, 14u) + (u << 1);
   const unsigned t2 = __umul24(b, (unsigned)(16 * m.ltx - 16)) + t;
-  return ((unsigned)v << 4) + t2;
+  return (v << 4) + t2;
 }
 
-__device__ __forceinline__ unsigned lut_level(const MapDev& m, int u, int v)
+// the stored 16-bit value is (level index * 8) = byte offset of the level's term in the term table
+__device__ __forceinline__ unsigned lut_level8(const MapDev& m, unsigned u, unsigned v)
 {
   return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(m.lut_tiles) + lut_byte_offset(m, u, v));
 }
@@ -78,7 +79,7 @@ __device__ __forceinline__ double recalc_factor(const MapDev& m, double px, doub
     return off_map_factor;
   if (m.cells8[ci + (size_t)cj * m.size_x] != -1)
     return non_free_factor;
-  const unsigned idx = lut_level(m, ci + kLutPad, cj + kLutPad);
+  const unsigned idx = lut_level8(m, (unsigned)(ci + kLutPad), (unsigned)(cj + kLutPad)) >> 3;
   const double d = (double)m.levels[idx];
   if (d < non_free_radius)
   {
@@ -122,75 +123,94 @@ __device__ __forceinline__ ScannerPose scanner_pose(double px, double py, double
 //     table indexed by the 16-bit level id of the cell, built on the host with the same
 //     libm expression as the reference (no transcendental in the loop, identical terms).
 // ---------------------------------------------------------------------------------------
-// One likelihood-field evaluation up to the cell.  (qx, qy) already hold
-// (scanner - origin)/res + 0.5 + size/2 + kLutPad, so the padded cell index is the truncation of
-// the end point (truncation == floor for every end point on the map or in the border, all of
-// which are positive); anything else is clamped into the border, which stores the off-map level.
+// Per-particle quantities of the likelihood-field family, computed once per update by k_field_prep:
+// scanner position in padded-cell units with the 0.5 rounding offset, size/2 and the border folded
+// in (so the padded cell index of an end point is the truncation of Q + R(theta)*B), and cos / sin
+// of the scanner heading.  A pose with a NaN / infinite / absurd component ends every beam off the
+// map in the reference ((int)NaN is INT_MIN on x86); it is stored as a far-away point with a zero
+// rotation so that the same happens here without per-beam tests.
+__device__ __forceinline__ double4 field_prep_of(const MapDev& M, double px, double py, double pth, double ax,
+                                                 double ay, double ath, bool* valid)
+{
+  ScannerPose sp = scanner_pose(px, py, pth, ax, ay, ath);
+  double Qx = ((sp.x - M.origin_x) / M.resolution + 0.5) + (double)(M.half_x + kLutPad);
+  double Qy = ((sp.y - M.origin_y) / M.resolution + 0.5) + (double)(M.half_y + kLutPad);
+  *valid = fabs(sp.c) <= 1.0 && fabs(sp.s) <= 1.0 && fabs(Qx) < 1073741824.0 && fabs(Qy) < 1073741824.0;
+  if (!*valid)
+  {
+    sp.c = 0.0;
+    sp.s = 0.0;
+    Qx = -1048576.0;
+    Qy = -1048576.0;
+  }
+  return make_double4(Qx, Qy, sp.c, sp.s);
+}
+
+// One likelihood-field evaluation up to the cell: byte offset of the end point's LUT entry.
+// |B| < 2^28 (checked when the beam table is staged) and |Q| < 2^30 keep the sum inside int range,
+// so the conversion never saturates onto the map.
 __device__ __forceinline__ unsigned field_cell(const MapDev& M, double c, double s, double qx, double qy,
                                                const double2 B)
 {
   const double vx = fma(c, B.x, fma(-s, B.y, qx));
   const double vy = fma(s, B.x, fma(c, B.y, qy));
-  // v_cvt_i32_f64 saturates; NaNs were removed when the particle and the beam table were prepared
-  const int u = clamp_i32((int)vx, kLutPad - 1, M.size_x + kLutPad);
-  const int v = clamp_i32((int)vy, kLutPad - 1, M.size_y + kLutPad);
-  return lut_byte_offset(M, u, v);
+  return lut_byte_offset(M, clamp_cell((int)vx, M.size_x), clamp_cell((int)vy, M.size_y));
 }
 
-constexpr int kFieldUnroll = 8;
+#ifndef BPF_FIELD_UNROLL
+#define BPF_FIELD_UNROLL 8
+#endif
+constexpr int kFieldUnroll = BPF_FIELD_UNROLL;
 
+// LDS layout of k_score_field: [term table (table_len doubles)] [beams (n_beams double2)]
 // COUNT_ONLY: pass 1 of the prob model's beam skipping -- only the per-beam agreement counts.
+#ifndef BPF_FIELD_WAVES
+#define BPF_FIELD_WAVES 4
+#endif
 template <bool COUNT_ONLY, bool TABLE_IN_LDS>
-__global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
+__global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const FieldScoreArgs A)
 {
+  if (A.skip_if_set != nullptr && *A.skip_if_set != 0)
+    return;  // kernels_window.hpp handles this update
   extern __shared__ __align__(16) unsigned char smem[];
-  double2* s_beams = reinterpret_cast<double2*>(smem);
-  double* s_table = reinterpret_cast<double*>(smem + (size_t)A.n_beams * sizeof(double2));
+  const int table_lds_len = (TABLE_IN_LDS && !COUNT_ONLY) ? A.table_len : 0;
+  double* s_table = reinterpret_cast<double*>(smem);
+  double2* s_beams = reinterpret_cast<double2*>(smem + (((size_t)table_lds_len * sizeof(double) + 15) & ~(size_t)15));
 
   const int tid = threadIdx.x;
   for (int i = tid; i < A.n_beams; i += 256)
     s_beams[i] = A.beams[i];
-  if (TABLE_IN_LDS && !COUNT_ONLY)
-    for (int i = tid; i < A.table_len; i += 256)
-      s_table[i] = A.table[i];
+  for (int i = tid; i < table_lds_len; i += 256)
+    s_table[i] = A.table[i];
   __syncthreads();
 
   const int lane = tid & 63;
-  const int sub = lane & 15;
   const int wave = tid >> 6;
-  const int n_groups = (A.n + 15) >> 4;
   const MapDev& M = A.map;
-  const double* table = TABLE_IN_LDS ? s_table : A.table;
+  const char* table_b = reinterpret_cast<const char*>(TABLE_IN_LDS ? s_table : A.table);
   const char* __restrict__ tiles = reinterpret_cast<const char*>(M.lut_tiles);
   const int n_beams = A.n_beams;
   double wsum = 0.0;  // this lane's share of the block's weight total
 
-  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4)
+  // Static partition: the grid is exactly one resident round of blocks and every wave owns a
+  // contiguous range of per_wave particles (a grid with a few blocks more than fit would run a
+  // second round for them and double the kernel time).  The range is walked 16 particles at a time.
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  const int p_begin = min(A.n, wid * A.per_wave), p_end = min(A.n, p_begin + A.per_wave);
+  for (int base = p_begin; base < p_end; base += 16)
   {
-    const int base = g << 4;
-    const int cnt = min(16, A.n - base);
-    const int pi = base + min(sub, cnt - 1);
-    const double px = A.p.x[pi], py = A.p.y[pi], pth = A.p.th[pi];
-    ScannerPose sp = scanner_pose(px, py, pth, A.sp_x, A.sp_y, A.sp_th);
-    // end point in padded cell units: trunc(Px + c*Bx - s*By), with 0.5, size/2 and the border
-    // folded into Px
-    double Px = ((sp.x - M.origin_x) / M.resolution + 0.5) + (double)(M.half_x + kLutPad);
-    double Py = ((sp.y - M.origin_y) / M.resolution + 0.5) + (double)(M.half_y + kLutPad);
-    // A pose with a NaN / infinite component puts every end point off the map in the reference
-    // ((int)NaN is INT_MIN on x86); do the same here once per particle instead of per beam.
-    if (!(fabs(sp.c) <= 1.0 && fabs(sp.s) <= 1.0 && fabs(Px) < 1e15 && fabs(Py) < 1e15))
-    {
-      sp.c = 0.0;
-      sp.s = 0.0;
-      Px = -4e18;
-      Py = -4e18;
-    }
-
+    const int cnt = min(16, p_end - base);
+    // one coalesced load brings the 16 particles' (Qx, Qy, cos, sin); each is then broadcast to the
+    // wave through scalar registers (a scalar load per particle would expose its latency 16 times)
+    const double4 ql = A.prep[base + min(lane & 15, cnt - 1)];
     double mine = 0.0;
     for (int k = 0; k < cnt; ++k)
     {
-      const double c = lane_bcast(sp.c, k), s = lane_bcast(sp.s, k);
-      const double qx = lane_bcast(Px, k), qy = lane_bcast(Py, k);
+      double4 q;
+      q.x = lane_bcast(ql.x, k);
+      q.y = lane_bcast(ql.y, k);
+      q.z = lane_bcast(ql.z, k);
+      q.w = lane_bcast(ql.w, k);
       double acc = 0.0;
       int b = lane;
       if (!COUNT_ONLY)
@@ -202,46 +222,47 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
           unsigned lv[kFieldUnroll];
 #pragma unroll
           for (int u = 0; u < kFieldUnroll; ++u)
-            off[u] = field_cell(M, c, s, qx, qy, s_beams[b + 64 * u]);
+            off[u] = field_cell(M, q.z, q.w, q.x, q.y, s_beams[b + 64 * u]);
 #pragma unroll
           for (int u = 0; u < kFieldUnroll; ++u)
             lv[u] = *reinterpret_cast<const uint16_t*>(tiles + off[u]);
 #pragma unroll
           for (int u = 0; u < kFieldUnroll; ++u)
-            acc += table[lv[u]];
+            acc += *reinterpret_cast<const double*>(table_b + lv[u]);
         }
       }
       for (; b < n_beams; b += 64)
       {
-        const unsigned off = field_cell(M, c, s, qx, qy, s_beams[b]);
+        const unsigned off = field_cell(M, q.z, q.w, q.x, q.y, s_beams[b]);
         const unsigned lv = *reinterpret_cast<const uint16_t*>(tiles + off);
         if (COUNT_ONLY)
         {
           // skip_level <= K, so the border's off-map level never counts (planar_scanner.cpp:441-451)
-          if ((int)lv < A.skip_level)
+          if ((int)(lv >> 3) < A.skip_level)
             atomicAdd(&A.obs_count[b], 1);
         }
         else
-          acc += table[lv];
+          acc += *reinterpret_cast<const double*>(table_b + lv);
       }
       if (!COUNT_ONLY)
       {
         const double tot = wave_sum(acc);
-        if (sub == k)
+        if (lane == k)
           mine = tot;
       }
     }
 
     if (!COUNT_ONLY && lane < cnt)
     {
+      const double sum = mine + A.extra_term;  // beams that end off the map for every pose
       double p;
       if (A.model == 1)  // likelihood field: p = 1 + sum pz^3
-        p = 1.0 + mine;
+        p = 1.0 + sum;
       else if (A.model == 3)  // Gompertz of the mean pz (planar_scanner.cpp:540-550,624-633)
       {
         if (A.n_valid > 0)
         {
-          double v = mine / A.n_valid;
+          double v = sum / A.n_valid;
           v = v * A.g.input_scale + A.g.input_shift;
           v = A.g.a * exp(-1.0 * A.g.b * exp(-1.0 * A.g.c * v));
           p = v + A.g.output_shift;
@@ -250,11 +271,11 @@ __global__ __launch_bounds__(256) void k_score_field(const FieldScoreArgs A)
           p = 1.0;
       }
       else  // prob: exp(sum log pz)
-        p = exp(mine);
-      const int q = base + lane;
-      double w = A.p.w[q] * p;
-      w *= recalc_factor(M, px, py, A.off_map_factor, A.non_free_factor, A.non_free_radius);
-      A.p.w[q] = w;
+        p = exp(sum);
+      const int i = base + lane;
+      double w = A.p.w[i] * p;
+      w *= recalc_factor(M, A.p.x[i], A.p.y[i], A.off_map_factor, A.non_free_factor, A.non_free_radius);
+      A.p.w[i] = w;
       wsum += w;
     }
   }

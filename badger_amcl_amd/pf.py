@@ -20,7 +20,7 @@ from . import _lib
 
 MODEL_BEAM, MODEL_LIKELIHOOD_FIELD, MODEL_LIKELIHOOD_FIELD_PROB, MODEL_LIKELIHOOD_FIELD_GOMPERTZ = 0, 1, 2, 3
 PF_RESAMPLE_MULTINOMIAL, PF_RESAMPLE_SYSTEMATIC = 0, 1
-OPT_CDF_SERIAL, OPT_COUNT_CELLS = 0, 1
+OPT_CDF_SERIAL, OPT_COUNT_CELLS, OPT_WINDOW_PATH = 0, 1, 2
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 
@@ -81,7 +81,7 @@ class Engine:
     def profile_get(self):
         p = _lib.Profile()
         self.check(self.lib.bpf_profile_get(self.h, C.byref(p)))
-        names = ["score", "reduce", "normalize", "cdf", "draw", "finalize", "k6", "k7"]
+        names = ["score", "reduce", "normalize", "cdf", "draw", "finalize", "score_window", "score_aux"]
         return {n: {"ms": p.ms[i], "launches": p.launches[i]} for i, n in enumerate(names)}
 
     def set_option(self, option, value):
@@ -91,6 +91,11 @@ class Engine:
         v = C.c_ulonglong()
         self.check(self.lib.bpf_get_cells_walked(self.h, C.byref(v), int(reset)))
         return v.value
+
+    def window_plan(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.check(self.lib.bpf_get_window_plan(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(used_window=bool(a.value), chunks_covered=b.value, chunks_total=c.value)
 
     def score_kernel_name(self):
         return self.lib.bpf_score_kernel_name(self.h).decode()

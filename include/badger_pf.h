@@ -40,7 +40,7 @@ enum
   BPF_ERR_HIP = 3,                /* a HIP runtime call failed; see bpf_last_error_message */
   BPF_ERR_UNSUPPORTED = 4,        /* e.g. w_diff > 0 needs the node's random_pose_fn_ callback */
   BPF_ERR_CDF_MISS = 5,           /* reference ROS_ASSERT(i < sample_count), particle_filter.cpp:399 */
-  BPF_ERR_LUT_LEVELS = 6,         /* distance LUT holds more than 65535 distinct values */
+  BPF_ERR_LUT_LEVELS = 6,         /* distance LUT holds more than 8190 distinct values */
   BPF_ERR_BEAM_STEP = 7,          /* beam model with range_count < max_beams: the reference never returns */
   BPF_ERR_CAPACITY = 8
 };
@@ -160,7 +160,8 @@ int bpf_pf_update_resample(bpf_engine* e);
 enum
 {
   BPF_OPT_CDF_SERIAL = 0,
-  BPF_OPT_COUNT_CELLS = 1
+  BPF_OPT_COUNT_CELLS = 1,
+  BPF_OPT_WINDOW_PATH = 2   /* default 0: 1 allows the LDS-window scoring kernels (device-side switch) */
 };
 int bpf_set_option(bpf_engine* e, int option, int value);
 /* cells visited by calcRange walks since the last reset (BPF_OPT_COUNT_CELLS) */
@@ -253,12 +254,14 @@ int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out);
 /* ------------------------------------------------------------------ measurement */
 enum
 {
-  BPF_K_SCORE = 0,     /* sensor scoring kernel (the dominant one) */
+  BPF_K_SCORE = 0,     /* sensor scoring kernel, gather form (k_score_field / k_score_beam / k_cloud_score) */
   BPF_K_REDUCE = 1,
   BPF_K_NORMALIZE = 2,
   BPF_K_CDF = 3,
   BPF_K_DRAW = 4,
   BPF_K_FINALIZE = 5,
+  BPF_K_SCORE_WINDOW = 6, /* sensor scoring kernel, LDS-window form (k_score_window) */
+  BPF_K_SCORE_AUX = 7,    /* its helpers: k_field_prep, k_field_windows, k_field_finish */
   BPF_K_COUNT = 8
 };
 typedef struct
@@ -274,6 +277,9 @@ int bpf_profile_reset(bpf_engine* e);
 int bpf_profile_get(bpf_engine* e, bpf_profile* out);
 /* Name of the scoring kernel as rocprofv3 prints it, for matching profiles/ summaries. */
 const char* bpf_score_kernel_name(const bpf_engine* e);
+/* Decision of the last likelihood-field update: *used_window = 1 when the LDS-window kernels did
+ * it, with how many of the 64-beam chunks the window plan expected to cover (synchronises). */
+int bpf_get_window_plan(bpf_engine* e, int* used_window, int* chunks_covered, int* chunks_total);
 
 #ifdef __cplusplus
 }
