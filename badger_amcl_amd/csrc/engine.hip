@@ -922,8 +922,18 @@ int build_cdf(bpf_engine* e, const double* w, int n)
       tiles = e->d_partials.p;
       hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles);
     }
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, tiles, nb, e->d_flags.p);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, e->d_cdf.p);
+    if (nb <= 256)
+    {
+      // few tiles: every block of the final pass forms its own offset (one launch less)
+      hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 0, e->d_cdf.p,
+                         e->d_flags.p);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, tiles, nb, e->d_flags.p);
+      hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 1, e->d_cdf.p,
+                         nullptr);
+    }
   }
   HIPCHK(e, hipGetLastError());
   return BPF_OK;

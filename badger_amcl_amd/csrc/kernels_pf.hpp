@@ -339,11 +339,28 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_tile_offsets(double* __r
   }
 }
 
+// tile_values holds exclusive tile offsets (offsets_ready != 0, after k_scan_tile_offsets) or the raw
+// tile sums (offsets_ready == 0): then every block adds up the sums of the tiles before it, left to
+// right -- the same running sum k_scan_tile_offsets forms -- which saves a launch when there are few tiles.
 __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __restrict__ w, int n,
-                                                             const double* __restrict__ tile_offsets,
-                                                             double* __restrict__ cdf)
+                                                             const double* __restrict__ tile_values,
+                                                             int offsets_ready, double* __restrict__ cdf,
+                                                             int* __restrict__ zero_word)
 {
   __shared__ double s_wave[4];
+  __shared__ double s_tile_off;
+  if (threadIdx.x == 0)
+  {
+    double off = 0.0;
+    if (offsets_ready)
+      off = tile_values[blockIdx.x];
+    else
+      for (int t = 0; t < (int)blockIdx.x; ++t)
+        off += tile_values[t];
+    s_tile_off = off;
+    if (blockIdx.x == 0 && zero_word != nullptr)
+      *zero_word = 0;  // the CDF-miss flag of the draw kernels that follow
+  }
   const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
   double v[BPF_RED_PER_THREAD];
   double run = 0.0;
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __re
   if (lane == 63)
     s_wave[wave] = incl;
   __syncthreads();
-  double off = tile_offsets[blockIdx.x];
+  double off = s_tile_off;
   for (int k = 0; k < wave; ++k)
     off += s_wave[k];
   off += incl - run;
