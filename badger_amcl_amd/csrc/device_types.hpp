@@ -15,17 +15,17 @@ namespace bpf
 //    clamped into [0, size+1] per axis (one unsigned min) and looked up without a bounds test.
 //    The stored value is level*8, the byte offset of the level's term in the per-scan table.
 //    Byte offset of padded cell (u, v):  (v&~7)*(16*ltx-16) + 16*v + (u&~7)*14 + 2*u.
-//  * notfree_tiles: one bit per cell (1 = not CELL_FREE), 8x8 cells per 64-bit word;
-//    bits of cells beyond the map edge inside a partial tile are 1.
+//  * cheb: for raycasts, one byte per cell of the map padded by one cell all round (row-major,
+//    padded cell (x+1, y+1), row length size_x+2): chessboard distance to the nearest cell that is
+//    not CELL_FREE or lies outside the map (the ring counts as blocked), capped at 255.
 //  * cells8: the tri-state grid narrowed to int8, row-major i + j*size_x.
 struct MapDev
 {
   const uint16_t* lut_tiles;
-  const uint64_t* notfree_tiles;
+  const uint8_t* cheb;
   const int8_t* cells8;
   const float* levels;
   int size_x, size_y;
-  int tiles_x, tiles_y;   // tiles of the un-padded grid (notfree_tiles)
   int ltx, lty;           // tiles per row / column of the padded LUT image
   int half_x, half_y;     // size/2, the centre offset of convertWorldToMap
   int n_levels;        // K; index K is reserved for "off map"

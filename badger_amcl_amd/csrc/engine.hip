@@ -138,7 +138,7 @@ struct bpf_engine
   std::vector<int8_t> h_cells8;
   std::vector<float> h_levels;
   DevBuf<uint16_t> d_lut_tiles;
-  DevBuf<uint64_t> d_notfree;
+  DevBuf<uint8_t> d_cheb;
   DevBuf<int8_t> d_cells8;
   DevBuf<float> d_levels;
   DevBuf<float> d_lut_f32;
@@ -169,6 +169,7 @@ struct bpf_engine
   DevBuf<double> d_prep_stats, d_chunk_partials;
   DevBuf<WindowPlan> d_plan;
   bool window_lds_attr_set = false;
+  bool beam_lds_attr_set = false;
   bool window_enabled = false;  // measured: no gain on wide clouds; opt-in via BPF_OPT_WINDOW_PATH
   bool last_used_window_path = false;
   DevBuf<unsigned long long> d_cells_walked;
@@ -756,6 +757,15 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     }
     if ((int)beams.size() > kMaxBeams)
       return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
+    // Rays of similar length walk together: order the beams by observed range so that the 64 lanes
+    // of one iteration finish their Bresenham walks at about the same step (the per-particle sum is
+    // order-independent up to rounding).  NaN ranges sort last.
+    std::stable_sort(beams.begin(), beams.end(), [](const BeamRec& a, const BeamRec& b) {
+      const bool an = a.obs != a.obs, bn = b.obs != b.obs;
+      if (an || bn)
+        return !an && bn;
+      return a.obs > b.obs;
+    });
     const size_t bytes = beams.size() * sizeof(BeamRec);
     ScanSlot* s;
     int rcode = acquire_slot(e, bytes, &s);
@@ -788,9 +798,21 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
       }
       A.cells_walked = e->d_cells_walked.p;
     }
-    const int n_groups = (n + 15) / 16;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(bytes, 1024)));
-    const int grid = std::max(1, std::min(blocks_for(n_groups, 4), e->n_cu * per_cu));
+    int api_blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, reinterpret_cast<const void*>(&k_score_beam), 256,
+                                                     bytes) != hipSuccess || api_blocks < 1)
+      api_blocks = 1;
+    const int per_cu = std::max(1, std::min(api_blocks, 6));
+    // rays differ in length, so cut the set ~4x finer than one range per resident wave
+    A.per_wave = std::max(1, blocks_for(n, e->n_cu * per_cu * 4 * 4));
+    const int grid = std::max(1, blocks_for(blocks_for(n, A.per_wave), 4));
+    A.block_partials = nullptr;
+    if (want_partials)
+    {
+      HIPCHK(e, e->d_block_partials.reserve((size_t)grid));
+      A.block_partials = e->d_block_partials.p;
+      e->fused_partials = grid;
+    }
     {
       ProfScope ps(e, BPF_K_SCORE);
       hipLaunchKernelGGL(k_score_beam, dim3(grid), dim3(256), bytes, e->stream, A);
@@ -1134,7 +1156,7 @@ void bpf_destroy(bpf_engine* e)
     (void)hipEventDestroy(ev);
   for (auto ev : e->ev_stop)
     (void)hipEventDestroy(ev);
-  e->d_lut_tiles.release(); e->d_notfree.release(); e->d_cells8.release(); e->d_levels.release();
+  e->d_lut_tiles.release(); e->d_cheb.release(); e->d_cells8.release(); e->d_levels.release();
   e->d_lut_f32.release(); e->d_edt_tmp.release(); e->d_obs_count.release();
   e->d_cells_walked.release();
   e->d_prep.release(); e->d_prep_stats.release(); e->d_chunk_partials.release(); e->d_plan.release();
@@ -1201,8 +1223,6 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
   MapDev& M = e->map;
   M.size_x = size_x;
   M.size_y = size_y;
-  M.tiles_x = (size_x + 7) / 8;
-  M.tiles_y = (size_y + 7) / 8;
   M.ltx = (size_x + 2 + 7) / 8 + 1;  // padded cells 0 .. size+1, plus a spare tile column for 8-aligned windows
   M.lty = (size_y + 2 + 7) / 8;
   if ((size_t)M.ltx * 16 >= (1u << 24) || (size_t)M.ltx * M.lty * 128 >= (1ull << 32))
@@ -1217,17 +1237,45 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
   e->h_cells8.resize(ncell);
   for (size_t i = 0; i < ncell; ++i)
     e->h_cells8[i] = (int8_t)cells[i];
-  std::vector<uint64_t> nf((size_t)M.tiles_x * M.tiles_y, ~0ull);
+  // chessboard distance to the nearest blocked cell on the padded grid: two raster sweeps of the
+  // 8-neighbour recurrence D = min(D, neighbour + 1), which is exact for the Chebyshev metric
+  const int pw = size_x + 2, ph = size_y + 2;
+  std::vector<uint16_t> dist((size_t)pw * ph, 0);
   for (int j = 0; j < size_y; ++j)
     for (int i = 0; i < size_x; ++i)
       if (cells[i + (size_t)j * size_x] == -1)
-        nf[(size_t)(j >> 3) * M.tiles_x + (i >> 3)] &= ~(1ull << (((j & 7) << 3) | (i & 7)));
+        dist[(size_t)(j + 1) * pw + (i + 1)] = 0xFFFF;
+  for (int y = 1; y < ph - 1; ++y)
+    for (int x = 1; x < pw - 1; ++x)
+    {
+      uint16_t& d = dist[(size_t)y * pw + x];
+      if (d == 0)
+        continue;
+      const uint16_t* up = &dist[(size_t)(y - 1) * pw + x];
+      uint16_t best = std::min(std::min(up[-1], up[0]), std::min(up[1], (&d)[-1]));
+      best = (uint16_t)std::min<int>(best + 1, 0xFFFF);
+      d = std::min(d, best);
+    }
+  for (int y = ph - 2; y >= 1; --y)
+    for (int x = pw - 2; x >= 1; --x)
+    {
+      uint16_t& d = dist[(size_t)y * pw + x];
+      if (d == 0)
+        continue;
+      const uint16_t* dn = &dist[(size_t)(y + 1) * pw + x];
+      uint16_t best = std::min(std::min(dn[-1], dn[0]), std::min(dn[1], (&d)[1]));
+      best = (uint16_t)std::min<int>(best + 1, 0xFFFF);
+      d = std::min(d, best);
+    }
+  std::vector<uint8_t> cheb((size_t)pw * ph);
+  for (size_t q = 0; q < cheb.size(); ++q)
+    cheb[q] = (uint8_t)std::min<int>(dist[q], 255);
   HIPCHK(e, e->d_cells8.reserve(ncell));
   HIPCHK(e, hipMemcpy(e->d_cells8.p, e->h_cells8.data(), ncell, hipMemcpyHostToDevice));
-  HIPCHK(e, e->d_notfree.reserve(nf.size()));
-  HIPCHK(e, hipMemcpy(e->d_notfree.p, nf.data(), nf.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_cheb.reserve(cheb.size()));
+  HIPCHK(e, hipMemcpy(e->d_cheb.p, cheb.data(), cheb.size(), hipMemcpyHostToDevice));
   M.cells8 = e->d_cells8.p;
-  M.notfree_tiles = e->d_notfree.p;
+  M.cheb = e->d_cheb.p;
   M.lut_tiles = nullptr;
   M.levels = nullptr;
   e->have_map = true;

@@ -306,17 +306,58 @@ struct BeamRec
   double tail_t;   // z_max (obs == range_max) or z_rand/range_max (obs < range_max) or 0
 };
 
-__device__ __forceinline__ bool cell_blocked(const MapDev& M, int cx, int cy, int& cur_tile, uint64_t& bits)
+// OccupancyMap::calcRange (occupancy_map.cpp:257-364) without visiting every cell.
+//
+// The reference walks an integer Bresenham line from the start cell towards the max-range end cell
+// and stops at the first cell that is off the map or not FREE.  The cell reached after j steps is a
+// closed form of j (major axis advances j, minor axis advances m_j = floor((2*j*dmin + dmaj)/(2*dmaj)),
+// which is exactly what the reference's running error term produces), so the walk can jump:
+// MapDev::cheb holds, per padded cell, the chessboard distance D to the nearest blocked cell
+// (blocked = not FREE or outside the map; capped at 255).  Every Bresenham step moves at most one
+// cell per axis, so the next D-1 cells of the line are free and the D-th is the next candidate:
+// jump D steps, look again.  The first blocked cell found this way is the one the reference finds,
+// and the returned distance uses the same integer deltas.  `walked` still counts the cells the
+// reference would have visited (j_hit + 1), the unit of the kernel's algorithmic bytes.
+__device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y0, int x1, int y1, double range_max,
+                                                  unsigned long long& walked)
 {
-  if (!((unsigned)cx < (unsigned)M.size_x && (unsigned)cy < (unsigned)M.size_y))
-    return true;
-  const int tile = (cy >> 3) * M.tiles_x + (cx >> 3);
-  if (tile != cur_tile)
+  if (x0 == x1 && y0 == y1)
+    return range_max;  // occupancy_map.cpp:279-280
+  // a start outside map + ring is "not valid" at the very first test: distance 0 (:316-334)
+  if (!((unsigned)(x0 + 1) <= (unsigned)(M.size_x + 1) && (unsigned)(y0 + 1) <= (unsigned)(M.size_y + 1)))
   {
-    bits = M.notfree_tiles[tile];
-    cur_tile = tile;
+    ++walked;
+    return 0.0;
   }
-  return (bits >> (((cy & 7) << 3) | (cx & 7))) & 1ull;
+  const int adx = abs(x1 - x0), ady = abs(y1 - y0);
+  const bool steep = ady > adx;
+  const int dmaj = steep ? ady : adx, dmin = steep ? adx : ady;
+  const int sx = (x0 < x1) ? 1 : -1, sy = (y0 < y1) ? 1 : -1;
+  const int maj_dx = steep ? 0 : sx, maj_dy = steep ? sy : 0;
+  const int min_dx = steep ? sx : 0, min_dy = steep ? 0 : sy;
+  const double inv2d = 1.0 / (2.0 * (double)dmaj);
+  const int last = dmaj + 1;  // the reference tests cells j = 0 .. dmaj + 1
+  const int stride = M.size_x + 2;
+  int j = 0;
+  for (;;)
+  {
+    // minor-axis advance after j steps; the 1e-6 absorbs the reciprocal's rounding (fractional parts
+    // of the true quotient are multiples of 1/(2*dmaj) >= 1e-4)
+    const int m = (int)fma((double)(2 * j * dmin + dmaj), inv2d, 1e-6);
+    const int x = x0 + maj_dx * j + min_dx * m, y = y0 + maj_dy * j + min_dy * m;
+    const int d = M.cheb[(y + 1) * stride + (x + 1)];
+    if (d == 0)
+    {
+      walked += (unsigned long long)(j + 1);
+      const int ddx = x - x0, ddy = y - y0;
+      return sqrt((double)(ddx * ddx + ddy * ddy)) * M.resolution;
+    }
+    if (j >= last)
+      break;
+    j = min(j + d, last);
+  }
+  walked += (unsigned long long)(last + 1);
+  return range_max;
 }
 
 struct BeamModelArgs
@@ -330,8 +371,12 @@ struct BeamModelArgs
   double off_map_factor, non_free_factor, non_free_radius;
   double range_max, z_hit, denom;
   unsigned long long* cells_walked;
+  int per_wave;
+  double* block_partials;
 };
 
+// Beam model: calcBeamModel (planar_scanner.cpp:168-234).  Wave = particle, lanes = beams (sorted by
+// observed range on the host so that the lanes of one iteration cast rays of similar length).
 __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
 {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -344,14 +389,15 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
   const int lane = tid & 63;
   const int sub = lane & 15;
   const int wave = tid >> 6;
-  const int n_groups = (A.n + 15) >> 4;
   const MapDev& M = A.map;
   unsigned long long walked = 0;
+  double wsum = 0.0;
 
-  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4)
+  const int wid = blockIdx.x * 4 + wave;
+  const int p_begin = min(A.n, wid * A.per_wave), p_end = min(A.n, p_begin + A.per_wave);
+  for (int base = p_begin; base < p_end; base += 16)
   {
-    const int base = g << 4;
-    const int cnt = min(16, A.n - base);
+    const int cnt = min(16, p_end - base);
     const int pi = base + min(sub, cnt - 1);
     const double px = A.p.x[pi], py = A.p.y[pi], pth = A.p.th[pi];
     const ScannerPose sp = scanner_pose(px, py, pth, A.sp_x, A.sp_y, A.sp_th);
@@ -370,43 +416,9 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
         const BeamRec B = s_beams[b];
         const double ca = c * B.cb - s * B.sb;  // cos(theta + bearing)
         const double sa = s * B.cb + c * B.sb;
-        int x0 = sx0, y0 = sy0;
-        int x1 = world_to_cell(ox + A.range_max * ca, M.origin_x, M.resolution, M.half_x);
-        int y1 = world_to_cell(oy + A.range_max * sa, M.origin_y, M.resolution, M.half_y);
-        double map_range = A.range_max;
-        if (!(x0 == x1 && y0 == y1))
-        {
-          const bool steep = abs(y1 - y0) > abs(x1 - x0);
-          if (steep)
-          {
-            int t = x0; x0 = y0; y0 = t;
-            t = x1; x1 = y1; y1 = t;
-          }
-          const int dx = abs(x1 - x0), dy = abs(y1 - y0);
-          const int stx = (x0 < x1) ? 1 : -1, sty = (y0 < y1) ? 1 : -1;
-          int err = 0, x = x0, y = y0;
-          int cur_tile = -1;
-          uint64_t bits = 0;
-          // dx+2 cells at most: the reference walks to x1 + step inclusive
-          for (int it = 0; it <= dx + 1; ++it)
-          {
-            ++walked;
-            const bool hit = steep ? cell_blocked(M, y, x, cur_tile, bits) : cell_blocked(M, x, y, cur_tile, bits);
-            if (hit)
-            {
-              const int ddx = x - x0, ddy = y - y0;
-              map_range = sqrt((double)(ddx * ddx + ddy * ddy)) * M.resolution;
-              break;
-            }
-            x += stx;
-            err += dy;
-            if (2 * err >= dx)
-            {
-              y += sty;
-              err -= dx;
-            }
-          }
-        }
+        const int x1 = world_to_cell(ox + A.range_max * ca, M.origin_x, M.resolution, M.half_x);
+        const int y1 = world_to_cell(oy + A.range_max * sa, M.origin_y, M.resolution, M.half_y);
+        const double map_range = calc_range_skip(M, sx0, sy0, x1, y1, A.range_max, walked);
         const double z = B.obs - map_range;
         double pz = 0.0;
         pz += A.z_hit * exp(-(z * z) / A.denom);
@@ -426,17 +438,28 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
       double w = A.p.w[q] * (1.0 + mine);
       w *= recalc_factor(M, px, py, A.off_map_factor, A.non_free_factor, A.non_free_radius);
       A.p.w[q] = w;
+      wsum += w;
     }
+  }
+  if (A.block_partials != nullptr)
+  {
+    __shared__ double s_part[4];
+    const double ws = wave_sum(wsum);
+    if (lane == 0)
+      s_part[wave] = ws;
+    __syncthreads();
+    if (tid == 0)
+      A.block_partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
   }
   if (A.cells_walked != nullptr)
   {
     // per-wave total, one atomic per wave
-    unsigned long long wsum = walked;
+    unsigned long long wsum2 = walked;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
-      wsum += __shfl_xor(wsum, off, 64);
+      wsum2 += __shfl_xor(wsum2, off, 64);
     if (lane == 0)
-      atomicAdd(A.cells_walked, wsum);
+      atomicAdd(A.cells_walked, wsum2);
   }
 }
 
