@@ -1945,10 +1945,18 @@ int score_cloud(bpf_engine* e, ParticlesDev p, int n, const float* points_xyz, i
   A.map = e->map3;
   A.table = e->d_cloud_table.p;
   A.partials = e->d_cloud_partials.p;
-  A.slabs = std::max(1, std::min(blocks_for(n, 4), std::max(1, (e->n_cu * 3) / n_chunks)));
+  A.slabs = std::max(1, std::min(blocks_for(n, 4), std::max(1, (e->n_cu * 6) / n_chunks)));
   {
+    // exact reciprocal?  1/res must fit 29 bits (so float * rinv is exact) and rinv*res must round to 1
+    const double rinv = e->map3.inv_resolution;
+    uint64_t bits;
+    std::memcpy(&bits, &rinv, 8);
+    const bool exact_rinv = (bits & ((1ull << 24) - 1)) == 0 && std::fabs(std::fma(rinv, e->map3.resolution, -1.0)) < 1.1e-16;
     ProfScope ps(e, BPF_K_SCORE);
-    hipLaunchKernelGGL(k_cloud_score, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
+    if (exact_rinv)
+      hipLaunchKernelGGL(k_cloud_score<true>, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
+    else
+      hipLaunchKernelGGL(k_cloud_score<false>, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
   }
   CloudFinishArgs F{};
   F.p = p;

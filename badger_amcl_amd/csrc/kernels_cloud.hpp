@@ -39,7 +39,7 @@ struct CloudModelDev
   double tf_quat[4];  // x y z w
 };
 
-constexpr int kCloudChunk = 4096;  // points per LDS chunk (48 KB as float SoA)
+constexpr int kCloudChunk = 2048;  // points per LDS chunk (24 KB as float SoA -> 6 blocks per CU)
 
 // point_cloud_scanner.cpp:231-248 restated: q = q_yaw * q_scanner (double), t = R_yaw*t_s + (x,y,0),
 // narrowed to float, Eigen's quaternion->matrix formula in float.
@@ -90,6 +90,15 @@ __global__ void k_cloud_affine(ParticlesDev p, int n, CloudModelDev M, float* __
 // octomap.cpp:102-107: floor(v / resolution + 0.5).  The quotient is formed as a corrected
 // reciprocal multiply (q = v*r; q += fma(-q, res, v)*r), which reproduces the correctly rounded
 // division except in vanishingly rare double-rounding cases.
+// When 1/resolution is exactly representable in <= 29 bits and rounds the same way (checked on the
+// host: resolution 0.05 -> 20, 0.1 -> 10, 0.025 -> 40 ...), v * rinv is exact for a float v and equals
+// the correctly rounded v / resolution, so one FMA gives the reference's value.
+__device__ __forceinline__ int voxel_of_exact(float v, double rinv)
+{
+  const double f = floor(fma((double)v, rinv, 0.5));
+  return (f == f) ? (int)f : 0x7fffffff;
+}
+
 __device__ __forceinline__ int voxel_of(float v, double res, double rinv)
 {
 #pragma clang fp contract(off)
@@ -113,6 +122,7 @@ struct CloudScoreArgs
   int slabs;
 };
 
+template <bool EXACT_RINV>
 __global__ __launch_bounds__(256) void k_cloud_score(const CloudScoreArgs A)
 {
 #pragma clang fp contract(off)
@@ -145,22 +155,46 @@ __global__ __launch_bounds__(256) void k_cloud_score(const CloudScoreArgs A)
     for (int k = 0; k < 12; ++k)
       R[k] = a[k];
     double acc = 0.0;
-    for (int q = lane; q < np; q += 64)
-    {
+    // one evaluation up to the column: byte index into distance_ratios of the voxel, or -1 off the map
+    auto locate = [&](int q, unsigned& col, unsigned& ck_out) -> bool {
       const float px = s_pts[0][q], py = s_pts[1][q], pz = s_pts[2][q];
       const float wx = ((R[0] * px + R[1] * py) + R[2] * pz) + R[9];
       const float wy = ((R[3] * px + R[4] * py) + R[5] * pz) + R[10];
       const float wz = ((R[6] * px + R[7] * py) + R[8] * pz) + R[11];
-      const int ci = voxel_of(wx, M.resolution, M.inv_resolution) - M.min_c[0];
-      const int cj = voxel_of(wy, M.resolution, M.inv_resolution) - M.min_c[1];
-      const int ck = voxel_of(wz, M.resolution, M.inv_resolution) - M.min_c[2];
-      unsigned level = 256;
-      if ((unsigned)ci <= (unsigned)span_x && (unsigned)cj <= (unsigned)span_y && (unsigned)ck <= (unsigned)span_z)
-      {
-        const uint32_t start = M.pose_indices[(unsigned)cj * (unsigned)M.width + (unsigned)ci];
-        level = M.distance_ratios[(size_t)start + (unsigned)ck];
-      }
-      acc += s_table[level];
+      const int ci = (EXACT_RINV ? voxel_of_exact(wx, M.inv_resolution) : voxel_of(wx, M.resolution, M.inv_resolution)) - M.min_c[0];
+      const int cj = (EXACT_RINV ? voxel_of_exact(wy, M.inv_resolution) : voxel_of(wy, M.resolution, M.inv_resolution)) - M.min_c[1];
+      const int ck = (EXACT_RINV ? voxel_of_exact(wz, M.inv_resolution) : voxel_of(wz, M.resolution, M.inv_resolution)) - M.min_c[2];
+      const bool ok = (unsigned)ci <= (unsigned)span_x && (unsigned)cj <= (unsigned)span_y && (unsigned)ck <= (unsigned)span_z;
+      col = ok ? (unsigned)cj * (unsigned)M.width + (unsigned)ci : 0u;
+      ck_out = ok ? (unsigned)ck : 0u;
+      return ok;
+    };
+    constexpr int U = 4;  // independent two-level gathers in flight per lane
+    int q = lane;
+    for (; q + 64 * (U - 1) < np; q += 64 * U)
+    {
+      unsigned col[U], ck[U], start[U], lvl[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        ok[u] = locate(q + 64 * u, col[u], ck[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        start[u] = M.pose_indices[col[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        lvl[u] = M.distance_ratios[(size_t)start[u] + ck[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        acc += s_table[ok[u] ? lvl[u] : 256u];
+    }
+    for (; q < np; q += 64)
+    {
+      unsigned col, ck;
+      const bool ok = locate(q, col, ck);
+      const unsigned start = M.pose_indices[col];
+      const unsigned lvl = M.distance_ratios[(size_t)start + ck];
+      acc += s_table[ok ? lvl : 256u];
     }
     const double tot = wave_sum(acc);
     if (lane == 0)
