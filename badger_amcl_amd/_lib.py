@@ -74,9 +74,10 @@ SIGNATURES = {
     "bpf_shard_score_planar": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double]),
     "bpf_shard_scalars_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "bpf_shard_normalize_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
-    "bpf_shard_build_cdf": (C.c_int, [_vp]),
-    "bpf_shard_draw_window_dev": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int,
-                                            _vp]),
+    "bpf_shard_build_cdf": (C.c_int, [_vp, _vp]),
+    "bpf_shard_draw_window_dev": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp,
+                                            C.c_int, _vp]),
+    "bpf_shard_tail_small_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bpf_shard_adopt_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bpf_shard_converged_dev": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "bpf_drand48_skip": (C.c_uint64, [C.c_uint64, C.c_uint64]),

@@ -221,6 +221,7 @@ struct bpf_engine
   DevBuf<int> d_keys, d_src_index, d_flags;  // d_flags[0] miss, [1] converged count
   DevBuf<double4> d_aos;
   PinnedBuf<int> h_keys;
+  PinnedBuf<double> h_targets;
   PinnedBuf<int> h_flags;
   PinnedBuf<FilterScalars> h_scalars;
   PinnedBuf<double4> h_aos;
@@ -1076,9 +1077,25 @@ int resample_systematic(bpf_engine* e)
   A.keys = e->d_keys.p;
   A.src_index = e->d_src_index.p;
   A.miss_flag = e->d_flags.p;
+  // The targets are a serial floating-point chain (particle_filter.cpp:337-341): target += delta, and
+  // target -= 1 once it passes 1.  A CPU core runs that dependency chain several times faster than a
+  // GPU lane, with the same IEEE arithmetic, so the host forms the targets and uploads them.
+  HIPCHK(e, e->h_targets.reserve((size_t)e->max_samples));
+  {
+    double t = start;
+    double* out = e->h_targets.p;
+    for (int i = 0; i < count; ++i)
+    {
+      out[i] = t;
+      t += delta;
+      if (t > 1.0)
+        t -= 1.0;
+    }
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_targets.p, e->h_targets.p, (size_t)count * sizeof(double), hipMemcpyHostToDevice,
+                           e->stream));
   {
     ProfScope ps(e, BPF_K_DRAW);
-    hipLaunchKernelGGL(k_systematic_targets, dim3(1), dim3(64), 0, e->stream, start, delta, count, e->d_targets.p);
     hipLaunchKernelGGL(k_systematic_select, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream, A);
   }
   HIPCHK(e, hipGetLastError());
@@ -1166,7 +1183,7 @@ void bpf_destroy(bpf_engine* e)
   e->d_cdf.release(); e->d_partials.release(); e->d_targets.release(); e->d_scalars.release();
   e->d_block_partials.release(); e->d_tile_sums.release();
   e->d_keys.release(); e->d_src_index.release(); e->d_flags.release(); e->d_aos.release();
-  e->h_keys.release(); e->h_flags.release(); e->h_scalars.release(); e->h_aos.release();
+  e->h_keys.release(); e->h_targets.release(); e->h_flags.release(); e->h_scalars.release(); e->h_aos.release();
   if (e->own_stream)
     (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -2057,9 +2074,19 @@ int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* an
   SampleSet& s = e->sets[e->cur];
   bool forced_zero = false;
   int rc = score_planar(e, s.dev(), e->sample_count, e->converged, ranges, angles, range_count, range_max,
-                        &forced_zero);
+                        &forced_zero, true);
   if (rc != BPF_OK)
     return rc;
+  if (e->fused_partials > 0)
+  {
+    // the scoring kernel left per-block partials: one small launch folds them into the local total
+    ProfScope ps(e, BPF_K_REDUCE);
+    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
+                       e->fused_partials, e->d_scalars.p, 0);
+    HIPCHK(e, hipGetLastError());
+    e->fused_partials = 0;
+    return BPF_OK;
+  }
   return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
 }
 
@@ -2082,20 +2109,24 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
   const int n = e->sample_count;
-  e->tile_sums_n = -1;
+  const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+  HIPCHK(e, e->d_tile_sums.reserve((size_t)nb));
   ProfScope ps(e, BPF_K_NORMALIZE);
-  hipLaunchKernelGGL(k_normalize_gathered, dim3(std::max(1, blocks_for(n, 256))), dim3(256), 0, e->stream, s.w.p, n,
+  hipLaunchKernelGGL(k_normalize_gathered, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
                      static_cast<const double*>(totals_dev), world, global_sample_count, e->d_scalars.p,
-                     e->alpha_slow, e->alpha_fast);
+                     e->alpha_slow, e->alpha_fast, e->d_tile_sums.p);
   HIPCHK(e, hipGetLastError());
+  e->tile_sums_n = n;
   return BPF_OK;
 }
 
-int bpf_shard_build_cdf(bpf_engine* e)
+int bpf_shard_build_cdf(bpf_engine* e, void* flags_dev)
 {
   if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
+  if (flags_dev)
+    HIPCHK(e, hipMemsetAsync(flags_dev, 0, sizeof(int), e->stream));
   int rc = build_cdf(e, e->sets[e->cur].w.p, e->sample_count);
   if (rc != BPF_OK)
     return rc;
@@ -2104,8 +2135,8 @@ int bpf_shard_build_cdf(bpf_engine* e)
   return BPF_OK;
 }
 
-int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev, int rank,
-                              int world, void* window_dev, int stride, void* flags_dev)
+int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev,
+                              int sums_are_totals, int rank, int world, void* window_dev, int stride, void* flags_dev)
 {
   if (!e || !e->have_pf || !sums_dev || !window_dev || !flags_dev || m1 <= m0 || stride < m1 - m0 || rank < 0 ||
       rank >= world)
@@ -2116,6 +2147,7 @@ int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m
   A.n_src = e->sample_count;
   A.cdf = e->d_cdf.p;
   A.sums = static_cast<const double*>(sums_dev);
+  A.sums_are_totals = sums_are_totals;
   A.rank = rank;
   A.world = world;
   A.m0 = m0;
@@ -2153,6 +2185,33 @@ int bpf_shard_adopt_dev(bpf_engine* e, const void* x_dev, const void* y_dev, con
   e->leaf_count = leaf_count;
   e->bin_count = bin_count;
   e->tile_sums_n = -1;
+  return BPF_OK;
+}
+
+int bpf_shard_tail_small_dev(bpf_engine* e, const void* x_all_dev, const void* y_all_dev, const void* theta_all_dev,
+                             int global_count, int lo, int hi, int leaf_count, int bin_count)
+{
+  if (!e || !e->have_pf || !x_all_dev || !y_all_dev || !theta_all_dev || global_count <= 0 || lo < 0 || hi < lo ||
+      hi > global_count)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (hi - lo > e->max_samples)
+    return e->fail(BPF_ERR_CAPACITY, "adopted shard larger than max_samples");
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& b = e->sets[e->cur ^ 1];
+  {
+    ProfScope ps(e, BPF_K_FINALIZE);
+    hipLaunchKernelGGL(k_shard_tail_small, dim3(1), dim3(1024), 0, e->stream, static_cast<const double*>(x_all_dev),
+                       static_cast<const double*>(y_all_dev), static_cast<const double*>(theta_all_dev), global_count,
+                       lo, hi, b.dev(), e->dist_threshold, e->d_scalars.p, e->d_flags.p + 1);
+  }
+  HIPCHK(e, hipGetLastError());
+  e->cur ^= 1;
+  e->sample_count = hi - lo;
+  e->leaf_count = leaf_count;
+  e->bin_count = bin_count;
+  e->tile_sums_n = -1;
+  e->converged_pending = true;
+  e->conv_n = global_count;
   return BPF_OK;
 }
 

@@ -250,16 +250,96 @@ __global__ __launch_bounds__(1024) void k_resample_tail_small(const double* __re
   }
 }
 
-// Sharded variant: the global total is the rank-ordered sum of the gathered per-shard totals;
-// thread 0 of block 0 also applies the running-average update with the global numbers.
-__global__ void k_normalize_gathered(double* __restrict__ w, int n, const double* __restrict__ totals, int world,
-                                     int global_n, FilterScalars* sc, double alpha_slow, double alpha_fast)
+// folds the scoring kernel's per-block weight partials into scalars[slot] (sharded path: the local total)
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_fold_partials(const double* __restrict__ partials, int n_partials,
+                                                                FilterScalars* sc, int slot)
 {
+  __shared__ double s_wave[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += BPF_RED_BLOCK)
+    acc += partials[i];
+  const double tot = block_sum_256(acc, s_wave);
+  if (threadIdx.x == 0)
+    sc->v[slot] = tot;
+}
+
+// Sharded tail for a small resampled set (one block): this rank adopts poses [lo, hi) of the assembled
+// window rows (weights 1/M, particle_filter.cpp:409,458-462) and evaluates updateConverged (:170-220)
+// over all M poses, which every rank holds.
+__global__ __launch_bounds__(1024) void k_shard_tail_small(const double* __restrict__ x_all,
+                                                          const double* __restrict__ y_all,
+                                                          const double* __restrict__ th_all, int m_total, int lo,
+                                                          int hi, ParticlesDev dst, double thr, FilterScalars* sc,
+                                                          int* __restrict__ count_out)
+{
+  __shared__ double s_x[16], s_y[16];
+  __shared__ int s_c[16];
+  const double weight = 1.0 / (double)m_total;
+  double ax = 0.0, ay = 0.0;
+  for (int i = threadIdx.x; i < m_total; i += 1024)
+  {
+    const double xv = x_all[i], yv = y_all[i];
+    ax += xv;
+    ay += yv;
+    if (i >= lo && i < hi)
+    {
+      dst.x[i - lo] = xv;
+      dst.y[i - lo] = yv;
+      dst.th[i - lo] = th_all[i];
+      dst.w[i - lo] = weight;
+    }
+  }
+  ax = wave_sum(ax);
+  ay = wave_sum(ay);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+    s_x[wave] = ax;
+    s_y[wave] = ay;
+  }
+  __syncthreads();
+  double sx = 0.0, sy = 0.0;
+  for (int k = 0; k < 16; ++k)
+  {
+    sx += s_x[k];
+    sy += s_y[k];
+  }
+  const double mx = sx / m_total, my = sy / m_total;
+  int c = 0;
+  for (int i = threadIdx.x; i < m_total; i += 1024)
+    if (fabs(x_all[i] - mx) <= thr && fabs(y_all[i] - my) <= thr)
+      c++;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    c += __shfl_xor(c, off, 64);
+  if (lane == 0)
+    s_c[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    int tot = 0;
+    for (int k = 0; k < 16; ++k)
+      tot += s_c[k];
+    *count_out = tot;
+    sc->v[3] = sx;
+    sc->v[4] = sy;
+  }
+}
+
+// Sharded variant: the global total is the rank-ordered sum of the gathered per-shard totals;
+// thread 0 of block 0 also applies the running-average update with the global numbers.  Tiles of
+// 2048 weights per block; each block leaves its tile's sum of normalised weights for the CDF.
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered(double* __restrict__ w, int n,
+                                                                     const double* __restrict__ totals, int world,
+                                                                     int global_n, FilterScalars* sc,
+                                                                     double alpha_slow, double alpha_fast,
+                                                                     double* __restrict__ tile_sums)
+{
+  __shared__ double s_wave[4];
   double total = 0.0;
   for (int r = 0; r < world; ++r)
     total += totals[r];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     sc->v[6] = total;
     if (total > 0.0)
@@ -278,12 +358,20 @@ __global__ void k_normalize_gathered(double* __restrict__ w, int n, const double
       sc->v[2] = wf;
     }
   }
-  if (i >= n)
-    return;
-  if (total > 0.0)
-    w[i] = w[i] / total;
-  else
-    w[i] = 1.0 / global_n;
+  const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
+  const double uniform = 1.0 / global_n;
+  double tsum = 0.0;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+    if (base + k < (size_t)n)
+    {
+      const double v = (total > 0.0) ? w[base + k] / total : uniform;
+      w[base + k] = v;
+      tsum += v;
+    }
+  const double tile = block_sum_256(tsum, s_wave);
+  if (threadIdx.x == 0)
+    tile_sums[blockIdx.x] = tile;
 }
 
 // ------------------------------------------------------------------ CDF (inclusive scan)
@@ -531,7 +619,8 @@ struct WindowArgs
   ParticlesDev src;
   int n_src;
   const double* cdf;     // local running sum, c[0] = 0
-  const double* sums;    // [world] per-shard CDF sums, rank order
+  const double* sums;    // [world] per-shard CDF sums (or weight totals), rank order
+  int sums_are_totals;   // 1: the shard's slice of [0,1) is total_r / sum(totals) by definition
   int rank, world;
   int m0, m1;
   uint64_t rng_state;
@@ -547,10 +636,21 @@ __global__ void k_draw_window(const WindowArgs A)
   const int m = A.m0 + o;
   if (m >= A.m1)
     return;
+  // Slice of the global CDF owned by this shard.  With CDF sums the slices tile [0, total) exactly.
+  // With weight totals (one exchange less) the slice of shard q is defined as total_q / T, the same
+  // quotient on every rank; the shard's own running sum is used inside it and its last particle
+  // takes whatever rounding leaves between the end of that sum and the end of the slice.
+  double T = 1.0;
+  if (A.sums_are_totals)
+  {
+    T = 0.0;
+    for (int r = 0; r < A.world; ++r)
+      T += A.sums[r];
+  }
   double offset = 0.0;
   for (int r = 0; r < A.rank; ++r)
-    offset += A.sums[r];
-  const double top = offset + A.sums[A.rank];
+    offset += A.sums_are_totals ? A.sums[r] / T : A.sums[r];
+  const double top = offset + (A.sums_are_totals ? A.sums[A.rank] / T : A.sums[A.rank]);
   const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
   const double r = ldexp((double)xs, -48);
   const bool last = A.rank == A.world - 1;
@@ -564,6 +664,8 @@ __global__ void k_draw_window(const WindowArgs A)
       atomicExch(A.flags, 1);  // reference: ROS_ASSERT(i < sample_count)
       i = A.n_src - 1;
     }
+    else if (!(r < offset + A.cdf[A.n_src]))
+      i = A.n_src - 1;  // inside the slice but past the shard's running sum (rounding): last particle
     else
     {
       int lo = 0, hi = A.n_src;  // offset + c[lo] <= r < offset + c[hi]

@@ -3,9 +3,12 @@ contiguous slice of the particle index space, `torch.distributed` (backend "nccl
 xGMI) carries the three small exchanges the path really has:
 
   update_sensor    all-gather of W per-shard weight totals (8 B each)
-  update_resample  all-gather of W per-shard CDF sums (8 B each), then per candidate-draw window
-                   one integer all-reduce(sum) of [6, window] int64 (pose bits + histogram key of
-                   every draw; exactly one shard writes each column, the others contribute 0)
+  update_resample  per candidate-draw window one integer all-reduce(sum) of [6, window] int64 (pose
+                   bits + histogram key of every draw; exactly one shard writes each column, the
+                   others contribute 0).  The shards' slices of the global CDF come from the totals
+                   gathered by the sensor update (slice_q = total_q / sum(totals), the same quotient on
+                   every rank), so no further exchange is needed; only when the weights were set by
+                   something else than update_sensor are the W local CDF sums all-gathered instead.
 
 Scoring itself shards with no communication.  The KLD stop rule (an ordered kd-tree replay) runs
 redundantly on every rank from the assembled key window, so all ranks agree on the sample count
@@ -57,17 +60,22 @@ class HipShardBackend:
         e = self.e
         e.check(e.lib.bpf_shard_normalize_dev(e.h, C.c_void_p(totals.data_ptr()), totals.numel(), int(global_n)))
 
-    def build_cdf(self):
-        self.e.check(self.e.lib.bpf_shard_build_cdf(self.e.h))
+    def build_cdf(self, flags):
+        self.e.check(self.e.lib.bpf_shard_build_cdf(self.e.h, C.c_void_p(flags.data_ptr())))
 
     def local_sum(self):
         return self.scalars[7:8]
 
-    def draw_window(self, rng, m0, m1, sums, rank, world, window, flags):
+    def draw_window(self, rng, m0, m1, sums, sums_are_totals, rank, world, window, flags):
         e = self.e
-        e.check(e.lib.bpf_shard_draw_window_dev(e.h, C.c_uint64(rng), m0, m1, C.c_void_p(sums.data_ptr()), rank, world,
-                                                C.c_void_p(window.data_ptr()), window.shape[1],
-                                                C.c_void_p(flags.data_ptr())))
+        e.check(e.lib.bpf_shard_draw_window_dev(e.h, C.c_uint64(rng), m0, m1, C.c_void_p(sums.data_ptr()),
+                                                int(sums_are_totals), rank, world, C.c_void_p(window.data_ptr()),
+                                                window.shape[1], C.c_void_p(flags.data_ptr())))
+
+    def tail_small(self, x_all, y_all, th_all, m, lo, hi, leaf, bins):
+        e = self.e
+        e.check(e.lib.bpf_shard_tail_small_dev(e.h, C.c_void_p(x_all.data_ptr()), C.c_void_p(y_all.data_ptr()),
+                                               C.c_void_p(th_all.data_ptr()), m, lo, hi, leaf, bins))
 
     def kld_reset(self):
         self.e.check(self.e.lib.bpf_kld_reset(self.e.h))
@@ -135,9 +143,14 @@ class ShardedFilter:
         self.sample_count = sum(self.counts)
         self.leaf_count = self.bin_count = 0
         self.windows_used = 0
+        self.totals = None  # per-shard weight totals of the last update_sensor (None: weights changed since)
 
     # ---- collectives (device tensors with nccl; staged through the host only for gloo + GPU)
     def _all_gather(self, t):
+        if not self.cpu_collectives and self.dist.get_backend() == "nccl":
+            out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, t.contiguous())
+            return out
         src = t.cpu() if self.cpu_collectives else t
         outs = [torch.empty_like(src) for _ in range(self.world)]
         self.dist.all_gather(outs, src.contiguous())
@@ -156,50 +169,62 @@ class ShardedFilter:
     # ---- Seam A
     def update_sensor(self, data):
         self.b.score(data)
-        totals = self._all_gather(self.b.local_total())
-        self.b.normalize(totals, self.sample_count)
+        self.totals = self._all_gather(self.b.local_total())
+        self.b.normalize(self.totals, self.sample_count)
 
     # ---- Seam B (multinomial, w_diff == 0)
     def update_resample(self):
         b, W = self.b, self.world
-        b.build_cdf()
-        sums = self._all_gather(b.local_sum())
+        b.build_cdf(self.flags)
+        if self.totals is not None:
+            sums, sums_are_totals = self.totals, True   # slices from the sensor update's totals
+        else:
+            sums, sums_are_totals = self._all_gather(b.local_sum()), False
         rng = b.rng_state()
         b.kld_reset()
-        self.flags.zero_()
         m0, stop = 0, -1
         win = max(1024, min(self.window_hint, self.max_global))
         self.windows_used = 0
+        windows = []
         while m0 < self.max_global and stop < 0:
             m1 = min(self.max_global, m0 + win)
             cnt = m1 - m0
-            window = self._windows.get(cnt)
+            window = self._windows.get((cnt, len(windows)))
             if window is None:
                 window = torch.zeros((6, cnt), dtype=torch.int64, device=self.device)
-                self._windows[cnt] = window
-            b.draw_window(rng, m0, m1, sums, self.rank, W, window, self.flags)
+                self._windows[(cnt, len(windows))] = window
+            b.draw_window(rng, m0, m1, sums, sums_are_totals, self.rank, W, window, self.flags)
             self._all_reduce_sum(window)
-            self.out[:, m0:m1] = window[0:3].view(torch.float64)
             keys = window[3:6].cpu().contiguous()  # the one host sync of the window
             stop = b.kld_feed(keys, cnt, m0)
+            windows.append((m0, cnt, window))
             self.windows_used += 1
             m0 = m1
             win *= 4
         M = stop if stop > 0 else self.max_global
         leaf, bins = b.kld_counts()
         lo, hi = (M * self.rank) // W, (M * (self.rank + 1)) // W
-        b.adopt(self.out[0, lo:hi], self.out[1, lo:hi], self.out[2, lo:hi], hi - lo, M, leaf, bins)
-        b.converged(self.out[0, :M], self.out[1, :M], M)
+        if len(windows) == 1 and M <= 8192:
+            # the common case: one window, small set -> adopt + weights + updateConverged in one launch
+            pose = windows[0][2][0:3].view(torch.float64)
+            b.tail_small(pose[0], pose[1], pose[2], M, lo, hi, leaf, bins)
+        else:
+            for (w0, cnt, window) in windows:
+                self.out[:, w0:w0 + cnt] = window[0:3].view(torch.float64)
+            b.adopt(self.out[0, lo:hi], self.out[1, lo:hi], self.out[2, lo:hi], hi - lo, M, leaf, bins)
+            b.converged(self.out[0, :M], self.out[1, :M], M)
         b.set_rng_state(b.skip(rng, 2 * M))
         self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
         self.sample_count = M
         self.leaf_count, self.bin_count = leaf, bins
         self.window_hint = max(1024, ((M + M // 4) + 1023) // 1024 * 1024)
+        self.totals = None  # the weights are 1/M now; the old totals no longer describe them
 
     def restore(self, counts):
         """Bench helper: the shards were put back by pf.restore(); reset the bookkeeping."""
         self.counts = list(counts)
         self.sample_count = sum(counts)
+        self.totals = None
 
     def state(self):
         st = self.b.state()

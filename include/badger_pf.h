@@ -222,16 +222,25 @@ int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr);
 /* ParticleFilter::updateSensor's normalisation (particle_filter.cpp:237-266) with the global
  * total = totals_dev[0] + ... + totals_dev[world-1] (added in rank order) and the global count */
 int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, int global_sample_count);
-/* local running sum c[0..n] of the shard's weights; its last element is copied to scalars[7] */
-int bpf_shard_build_cdf(bpf_engine* e);
+/* local running sum c[0..n] of the shard's weights; its last element is copied to scalars[7];
+ * flags_dev (nullable): an int the call zeroes, the CDF-miss flag of the draw windows that follow */
+int bpf_shard_build_cdf(bpf_engine* e, void* flags_dev);
 /* Candidate draws m in [m0, m1) of the multinomial resampler (particle_filter.cpp:381-414) from
  * the drand48 state `rng_state48`.  The shard owns the draws whose r lies in
  * [offset, offset + sums_dev[rank]) with offset = sums_dev[0] + ... + sums_dev[rank-1].
+ * sums_are_totals = 1: sums_dev holds the gathered WEIGHT TOTALS of the last sensor update instead
+ * (no second exchange): shard q's slice is then total_q / sum(totals), formed identically on every
+ * rank; inside it the shard's own running sum is used and its last particle absorbs the rounding.
  * window_dev is int64[6][stride]: rows 0-2 the bit patterns of the selected pose (x, y, theta),
  * rows 3-5 its histogram key; column m - m0.  Owned draws are written, all others are zeroed, so
  * an integer sum over the ranks assembles the window exactly.  flags_dev[0] is set on a CDF miss. */
-int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev, int rank,
-                              int world, void* window_dev, int stride, void* flags_dev);
+int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev,
+                              int sums_are_totals, int rank, int world, void* window_dev, int stride, void* flags_dev);
+/* Tail of the sharded resample for a small set (global_count <= 8192), one launch: adopt poses
+ * [lo, hi) of the assembled arrays with weight 1/global_count, flip the sets, and evaluate
+ * updateConverged over all global_count poses. */
+int bpf_shard_tail_small_dev(bpf_engine* e, const void* x_all_dev, const void* y_all_dev, const void* theta_all_dev,
+                             int global_count, int lo, int hi, int leaf_count, int bin_count);
 /* Become the resampled shard: copy `count` poses from device arrays, weight 1/global_count each
  * (particle_filter.cpp:409,458-462), flip the ping-pong sets. */
 int bpf_shard_adopt_dev(bpf_engine* e, const void* x_dev, const void* y_dev, const void* theta_dev, int count,

@@ -65,7 +65,8 @@ class OracleShardBackend:
         else:
             self.samples[:, 3] = 1.0 / global_n
 
-    def build_cdf(self):
+    def build_cdf(self, flags):
+        flags[0] = 0
         c = np.zeros(self.samples.shape[0] + 1)
         run = 0.0
         for i, w in enumerate(self.samples[:, 3]):
@@ -77,8 +78,13 @@ class OracleShardBackend:
     def local_sum(self):
         return self._sum
 
-    def draw_window(self, rng, m0, m1, sums, rank, world, window, flags):
+    def draw_window(self, rng, m0, m1, sums, sums_are_totals, rank, world, window, flags):
         s = sums.tolist()
+        if sums_are_totals:
+            T = 0.0
+            for v in s:
+                T += v
+            s = [v / T for v in s]
         offset = 0.0
         for r in range(rank):
             offset += s[r]
@@ -95,6 +101,8 @@ class OracleShardBackend:
                 continue
             if not r < top:
                 flags[0] = 1
+                i = n - 1
+            elif not r < offset + self.cdf[n]:
                 i = n - 1
             else:
                 lo, hi = 0, n
@@ -126,6 +134,10 @@ class OracleShardBackend:
 
     def kld_counts(self):
         return self.tree.leaf_count(), self.tree.node_count()
+
+    def tail_small(self, x_all, y_all, th_all, m, lo, hi, leaf, bins):
+        self.adopt(x_all[lo:hi], y_all[lo:hi], th_all[lo:hi], hi - lo, m, leaf, bins)
+        self.converged(x_all, y_all, m)
 
     def adopt(self, x, y, th, count, global_m, leaf, bins):
         s = np.zeros((count, 4))
