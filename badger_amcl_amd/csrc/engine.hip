@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -221,6 +223,9 @@ struct bpf_engine
   DevBuf<int> d_keys, d_src_index, d_flags;  // d_flags[0] miss, [1] converged count
   DevBuf<double4> d_aos;
   PinnedBuf<int> h_keys;
+  PinnedBuf<unsigned> h_done;
+  unsigned done_generation = 0;
+  bool zero_copy_keys = true;
   PinnedBuf<double> h_targets;
   PinnedBuf<int> h_flags;
   PinnedBuf<FilterScalars> h_scalars;
@@ -714,6 +719,9 @@ int ensure_scalars(bpf_engine* e)
   HIPCHK(e, e->d_flags.reserve(8));
   HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, 8 * sizeof(int), e->stream));
   HIPCHK(e, e->h_flags.reserve(8));
+  HIPCHK(e, e->h_done.reserve(16));
+  e->h_done.p[0] = 0;
+  e->zero_copy_keys = getenv("BPF_NO_ZEROCOPY") == nullptr;
   return BPF_OK;
 }
 
@@ -1014,19 +1022,56 @@ int resample_multinomial(bpf_engine* e)
     A.src_index = e->d_src_index.p;
     A.miss_flag = e->d_flags.p;
     A.sharded = 0;
+    const int wn = m1 - m0;
+    // Keys go straight into pinned host memory and the last block publishes a generation number
+    // there: the host polls that word instead of paying for a copy plus a stream synchronisation.
+    const bool zero_copy = e->zero_copy_keys && wn <= (1 << 20);
+    if (zero_copy)
+    {
+      A.host_keys = e->h_keys.p;
+      A.host_stride = wn;
+      A.done_counter = reinterpret_cast<unsigned*>(e->d_flags.p + 4);
+      A.host_done = reinterpret_cast<volatile unsigned*>(e->h_done.p);
+      A.generation = ++e->done_generation;
+    }
     {
       ProfScope ps(e, BPF_K_DRAW);
-      hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(m1 - m0, 256)), dim3(256), 0, e->stream, A);
+      hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(wn, 256)), dim3(256), 0, e->stream, A);
     }
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)(m1 - m0) * 3 * sizeof(int), hipMemcpyDeviceToHost,
-                             e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    bool have_keys = false;
+    if (zero_copy)
+    {
+      // bounded spin (a kernel of ~10 us): fall back to a plain synchronise if it takes implausibly long
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0;; ++spins)
+      {
+        if (__atomic_load_n(e->h_done.p, __ATOMIC_ACQUIRE) == A.generation)
+        {
+          have_keys = true;
+          break;
+        }
+        if ((spins & 1023) == 1023 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+          break;
+        __builtin_ia32_pause();
+      }
+    }
+    int k_stride = wn;
+    if (!have_keys)
+    {
+      HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)wn * 3 * sizeof(int), hipMemcpyDeviceToHost,
+                               e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      k_stride = 0;  // AoS triples from the device buffer
+    }
     e->resample_windows++;
     const int* keys = e->h_keys.p;
     for (int m = m0; m < m1; ++m)
     {
-      const int* k = &keys[3 * (m - m0)];
+      const int o = m - m0;
+      const int k[3] = { k_stride ? keys[o] : keys[3 * o], k_stride ? keys[k_stride + o] : keys[3 * o + 1],
+                         k_stride ? keys[2 * k_stride + o] : keys[3 * o + 2] };
       if (e->seen.first_time(k[0], k[1], k[2]))
       {
         e->hist.insert(k[0], k[1], k[2]);
@@ -1183,7 +1228,7 @@ void bpf_destroy(bpf_engine* e)
   e->d_cdf.release(); e->d_partials.release(); e->d_targets.release(); e->d_scalars.release();
   e->d_block_partials.release(); e->d_tile_sums.release();
   e->d_keys.release(); e->d_src_index.release(); e->d_flags.release(); e->d_aos.release();
-  e->h_keys.release(); e->h_targets.release(); e->h_flags.release(); e->h_scalars.release(); e->h_aos.release();
+  e->h_keys.release(); e->h_targets.release(); e->h_done.release(); e->h_flags.release(); e->h_scalars.release(); e->h_aos.release();
   if (e->own_stream)
     (void)hipStreamDestroy(e->own_stream);
   delete e;

@@ -548,11 +548,19 @@ struct DrawArgs
   double cdf_offset;
   int sharded;
   int is_last_shard;
+  // zero-copy hand-off of the keys to the host (nullable): keys also go, as three rows of
+  // `host_stride` ints, straight into pinned host memory; the block that finishes last publishes
+  // `generation` in *host_done so the host can poll instead of issuing a copy and a stream sync
+  int* host_keys;
+  int host_stride;
+  unsigned* done_counter;       // device word, 0 between launches
+  volatile unsigned* host_done; // pinned host word
+  unsigned generation;
 };
 
 // Multinomial resampler body for w_diff == 0 (particle_filter.cpp:381-414): draw m consumes
 // stream elements 2m+1 (compared with w_diff) and 2m+2 (r).
-__global__ void k_draw_select(const DrawArgs A)
+__device__ __forceinline__ void draw_select_body(const DrawArgs& A)
 {
   const int m = A.m0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= A.m1)
@@ -607,7 +615,43 @@ __global__ void k_draw_select(const DrawArgs A)
     A.dst.th[m] = th;
   }
   A.src_index[o] = i;
-  pose_key(x, y, th, &A.keys[3 * o]);
+  int key[3];
+  pose_key(x, y, th, key);
+  A.keys[3 * o] = key[0];
+  A.keys[3 * o + 1] = key[1];
+  A.keys[3 * o + 2] = key[2];
+  if (A.host_keys != nullptr)
+  {
+    A.host_keys[o] = key[0];
+    A.host_keys[A.host_stride + o] = key[1];
+    A.host_keys[2 * A.host_stride + o] = key[2];
+  }
+}
+
+// Completion hand-off of k_draw_select's zero-copy keys: every thread makes its host-memory stores
+// visible system-wide, the block checks in on a device counter, and the last block to do so
+// publishes the generation number in pinned host memory (and re-arms the counter).
+__device__ __forceinline__ void publish_when_last(unsigned* counter, volatile unsigned* host_done, unsigned generation)
+{
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const unsigned prev = atomicAdd(counter, 1u);
+    if (prev == gridDim.x - 1)
+    {
+      *counter = 0;
+      __threadfence_system();
+      __hip_atomic_store(const_cast<unsigned*>(host_done), generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__global__ void k_draw_select(const DrawArgs A)
+{
+  draw_select_body(A);
+  if (A.host_keys != nullptr)
+    publish_when_last(A.done_counter, A.host_done, A.generation);
 }
 
 // Sharded multinomial draws: every shard evaluates every draw of the window, keeps the ones whose
