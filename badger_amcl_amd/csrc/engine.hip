@@ -421,8 +421,8 @@ int acquire_slot(bpf_engine* e, size_t bytes, ScanSlot** out)
   }
   if (!s.done)
     HIPCHK(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-  HIPCHK(e, s.host.reserve(bytes));
-  HIPCHK(e, s.dev.reserve(bytes));
+  HIPCHK(e, s.host.reserve((bytes + 31) & ~(size_t)15));  // whole 16-byte words are copied
+  HIPCHK(e, s.dev.reserve((bytes + 31) & ~(size_t)15));
   *out = &s;
   return BPF_OK;
 }
@@ -438,6 +438,7 @@ struct FieldScan
 {
   int n_valid = 0;             // beams that pass the range_max / NaN tests
   int n_staged = 0;            // of those, the ones uploaded (all, or the kept ones of beam skipping)
+  bool copy_pending = false;   // pinned staging not yet copied to the device slot
   int n_always_off = 0;        // valid beams too long / non-finite to stage: off the map for every pose
   double off_map_term = 0.0;   // table[K]
   int n_slots = 0;             // beam_ind range of the prob model
@@ -564,7 +565,9 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
     e->term_key = key;
   }
   fs->off_map_term = table[K];
-  HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs->bytes, hipMemcpyHostToDevice, e->stream));
+  // the copy to the device slot is done by k_field_prep (launch_field) unless the staging block is
+  // larger than what its grid covers
+  fs->copy_pending = true;
   *slot_out = s;
   return BPF_OK;
 }
@@ -603,9 +606,15 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   HIPCHK(e, e->d_prep.reserve((size_t)n));
   HIPCHK(e, e->d_prep_stats.reserve((size_t)prep_blocks * kPrepStats));
   {
+    const int n16 = (int)((fs.bytes + 15) / 16);
+    const bool ride = fs.copy_pending && n16 <= prep_blocks * 256;
+    if (fs.copy_pending && !ride)
+      HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs.bytes, hipMemcpyHostToDevice, e->stream));
     ProfScope pa(e, BPF_K_SCORE_AUX);
     hipLaunchKernelGGL(k_field_prep, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y, A.sp_th,
-                       e->d_prep.p, e->d_prep_stats.p);
+                       e->d_prep.p, e->d_prep_stats.p,
+                       ride ? reinterpret_cast<const uint4*>(s->host.p) : static_cast<const uint4*>(nullptr),
+                       reinterpret_cast<uint4*>(s->dev.p), n16);
   }
   A.prep = e->d_prep.p;
   // One resident round: blocks per CU = what registers, LDS and the SGPR rule admit (the occupancy

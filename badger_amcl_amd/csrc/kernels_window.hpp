@@ -49,10 +49,21 @@ struct WindowPlan
 };
 
 // ---------------------------------------------------------------------------------------
+// The per-scan staging block (beam table + term table, ~25 KB, written by the host into pinned
+// memory) rides along: the first blocks copy it into the device slot the scoring kernel reads, which
+// saves a separate copy operation on the stream (stage_src == nullptr: already copied).
 __global__ __launch_bounds__(256) void k_field_prep(ParticlesDev p, int n, MapDev M, double ax, double ay, double ath,
-                                                   double4* __restrict__ prep, double* __restrict__ stats)
+                                                   double4* __restrict__ prep, double* __restrict__ stats,
+                                                   const uint4* __restrict__ stage_src, uint4* __restrict__ stage_dst,
+                                                   int stage_n16)
 {
   __shared__ double s_red[4][kPrepStats];
+  if (stage_src != nullptr)
+  {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < stage_n16)
+      stage_dst[q] = stage_src[q];
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   double v[kPrepStats] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   if (i < n)
