@@ -611,10 +611,13 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
     if (fs.copy_pending && !ride)
       HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs.bytes, hipMemcpyHostToDevice, e->stream));
     ProfScope pa(e, BPF_K_SCORE_AUX);
-    hipLaunchKernelGGL(k_field_prep, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y, A.sp_th,
-                       e->d_prep.p, e->d_prep_stats.p,
-                       ride ? reinterpret_cast<const uint4*>(s->host.p) : static_cast<const uint4*>(nullptr),
-                       reinterpret_cast<uint4*>(s->dev.p), n16);
+    const uint4* src = ride ? reinterpret_cast<const uint4*>(s->host.p) : static_cast<const uint4*>(nullptr);
+    if (e->window_enabled)
+      hipLaunchKernelGGL(k_field_prep<true>, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
+                         A.sp_th, e->d_prep.p, e->d_prep_stats.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
+    else
+      hipLaunchKernelGGL(k_field_prep<false>, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
+                         A.sp_th, e->d_prep.p, e->d_prep_stats.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
   }
   A.prep = e->d_prep.p;
   // One resident round: blocks per CU = what registers, LDS and the SGPR rule admit (the occupancy

@@ -52,6 +52,7 @@ struct WindowPlan
 // The per-scan staging block (beam table + term table, ~25 KB, written by the host into pinned
 // memory) rides along: the first blocks copy it into the device slot the scoring kernel reads, which
 // saves a separate copy operation on the stream (stage_src == nullptr: already copied).
+template <bool WITH_STATS>
 __global__ __launch_bounds__(256) void k_field_prep(ParticlesDev p, int n, MapDev M, double ax, double ay, double ath,
                                                    double4* __restrict__ prep, double* __restrict__ stats,
                                                    const uint4* __restrict__ stage_src, uint4* __restrict__ stage_dst,
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(256) void k_field_prep(ParticlesDev p, int n, MapDe
     }
     prep[i] = q;
   }
+  if (!WITH_STATS)
+    return;  // the cloud statistics only feed the window planner
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < kPrepStats; ++k)
