@@ -204,51 +204,113 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
     // wave through scalar registers (a scalar load per particle would expose its latency 16 times)
     const double4 ql = A.prep[base + min(lane & 15, cnt - 1)];
     double mine = 0.0;
-    for (int k = 0; k < cnt; ++k)
+    if (!COUNT_ONLY)
     {
-      double4 q;
-      q.x = lane_bcast(ql.x, k);
-      q.y = lane_bcast(ql.y, k);
-      q.z = lane_bcast(ql.z, k);
-      q.w = lane_bcast(ql.w, k);
-      double acc = 0.0;
+      // Beam-batch outer / particle inner: a lane's kFieldUnroll beams are read from LDS once per
+      // 16 particles and stay in registers; every lane keeps one running sum per particle, so the
+      // cross-lane reduction happens once per group (transposed, below) instead of once per particle.
+      double accs[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        accs[k] = 0.0;
       int b = lane;
-      if (!COUNT_ONLY)
+      for (; b + 64 * (kFieldUnroll - 1) < n_beams; b += 64 * kFieldUnroll)
       {
-        // full batches: kFieldUnroll independent gathers in flight per lane
-        for (; b + 64 * (kFieldUnroll - 1) < n_beams; b += 64 * kFieldUnroll)
+        double2 B[kFieldUnroll];
+#pragma unroll
+        for (int u = 0; u < kFieldUnroll; ++u)
+          B[u] = s_beams[b + 64 * u];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
         {
-          unsigned off[kFieldUnroll];
-          unsigned lv[kFieldUnroll];
+          if (k < cnt)
+          {
+            const double qx = lane_bcast(ql.x, k), qy = lane_bcast(ql.y, k);
+            const double c = lane_bcast(ql.z, k), s = lane_bcast(ql.w, k);
+            unsigned lv[kFieldUnroll];
 #pragma unroll
-          for (int u = 0; u < kFieldUnroll; ++u)
-            off[u] = field_cell(M, q.z, q.w, q.x, q.y, s_beams[b + 64 * u]);
+            for (int u = 0; u < kFieldUnroll; ++u)
+              lv[u] = *reinterpret_cast<const uint16_t*>(tiles + field_cell(M, c, s, qx, qy, B[u]));
 #pragma unroll
-          for (int u = 0; u < kFieldUnroll; ++u)
-            lv[u] = *reinterpret_cast<const uint16_t*>(tiles + off[u]);
-#pragma unroll
-          for (int u = 0; u < kFieldUnroll; ++u)
-            acc += *reinterpret_cast<const double*>(table_b + lv[u]);
+            for (int u = 0; u < kFieldUnroll; ++u)
+              accs[k] += *reinterpret_cast<const double*>(table_b + lv[u]);
+          }
         }
       }
       for (; b < n_beams; b += 64)
       {
-        const unsigned off = field_cell(M, q.z, q.w, q.x, q.y, s_beams[b]);
-        const unsigned lv = *reinterpret_cast<const uint16_t*>(tiles + off);
-        if (COUNT_ONLY)
+        const double2 B1 = s_beams[b];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
         {
+          if (k < cnt)
+          {
+            const double qx = lane_bcast(ql.x, k), qy = lane_bcast(ql.y, k);
+            const double c = lane_bcast(ql.z, k), s = lane_bcast(ql.w, k);
+            const unsigned lv = *reinterpret_cast<const uint16_t*>(tiles + field_cell(M, c, s, qx, qy, B1));
+            accs[k] += *reinterpret_cast<const double*>(table_b + lv);
+          }
+        }
+      }
+      // transposed reduction: 16 per-particle partials x 64 lanes -> lane k (k < 16) holds particle k's sum.
+      // Step h: lanes exchange the half of their values they do not keep (xor 32, 16, 8, 4 halve the
+      // value count 16 -> 1), then two plain butterfly steps finish (xor 2, 1).
+      {
+        // after the exchanges lane L keeps the value of particle (L >> 2) & 15 ... built up bit by bit
+        double v8[8], v4[4], v2[2], v1;
+        const bool up32 = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+          const double keep = up32 ? accs[i + 8] : accs[i];
+          const double give = up32 ? accs[i] : accs[i + 8];
+          v8[i] = keep + __shfl_xor(give, 32, 64);
+        }
+        const bool up16 = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+          const double keep = up16 ? v8[i + 4] : v8[i];
+          const double give = up16 ? v8[i] : v8[i + 4];
+          v4[i] = keep + __shfl_xor(give, 16, 64);
+        }
+        const bool up8 = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+          const double keep = up8 ? v4[i + 2] : v4[i];
+          const double give = up8 ? v4[i] : v4[i + 2];
+          v2[i] = keep + __shfl_xor(give, 8, 64);
+        }
+        const bool up4 = (lane & 4) != 0;
+        {
+          const double keep = up4 ? v2[1] : v2[0];
+          const double give = up4 ? v2[0] : v2[1];
+          v1 = keep + __shfl_xor(give, 4, 64);
+        }
+        v1 += __shfl_xor(v1, 2, 64);
+        v1 += __shfl_xor(v1, 1, 64);
+        // lane L now holds the total of particle p(L) = 8*[L&32] + 4*[L&16] + 2*[L&8] + 1*[L&4]
+        const int owner = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        // route it to lane == particle index for the epilogue
+        const int src_lane = ((lane >> 3) & 1) * 32 + ((lane >> 2) & 1) * 16 + ((lane >> 1) & 1) * 8 + (lane & 1) * 4;
+        mine = __shfl(v1, src_lane, 64);  // lane k (< 16) reads a lane whose owner is k
+        (void)owner;
+      }
+    }
+    else
+    {
+      for (int k = 0; k < cnt; ++k)
+      {
+        const double qx = lane_bcast(ql.x, k), qy = lane_bcast(ql.y, k);
+        const double c = lane_bcast(ql.z, k), s = lane_bcast(ql.w, k);
+        for (int b = lane; b < n_beams; b += 64)
+        {
+          const unsigned lv = *reinterpret_cast<const uint16_t*>(tiles + field_cell(M, c, s, qx, qy, s_beams[b]));
           // skip_level <= K, so the border's off-map level never counts (planar_scanner.cpp:441-451)
           if ((int)(lv >> 3) < A.skip_level)
             atomicAdd(&A.obs_count[b], 1);
         }
-        else
-          acc += *reinterpret_cast<const double*>(table_b + lv);
-      }
-      if (!COUNT_ONLY)
-      {
-        const double tot = wave_sum(acc);
-        if (lane == k)
-          mine = tot;
       }
     }
 
