@@ -16,6 +16,10 @@ class PFState(C.Structure):
                 ("last_status", C.c_int), ("resample_windows", C.c_int), ("evals", C.c_longlong)]
 
 
+class Cluster(C.Structure):
+    _fields_ = [("count", C.c_int), ("weight", C.c_double), ("mean", C.c_double * 3), ("cov", C.c_double * 5)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * BPF_K_COUNT), ("launches", C.c_longlong * BPF_K_COUNT)]
 
@@ -62,6 +66,17 @@ SIGNATURES = {
     "bpf_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "bpf_get_cells_walked": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
     "bpf_pf_get_state": (C.c_int, [_vp, C.POINTER(PFState)]),
+    "bpf_pf_compute_cluster_stats": (C.c_int, [_vp, _ip, _dp, _dp]),
+    "bpf_pf_get_cluster": (C.c_int, [_vp, C.c_int, C.POINTER(Cluster)]),
+    "bpf_pf_get_max_weight_pose": (C.c_int, [_vp, _dp, _dp]),
+    "bpf_map2d_build_distances_lut_reference": (C.c_int, [_vp, C.c_double]),
+    "bpf_wire_laserscan_to_planar": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_double,
+                                               C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]),
+    "bpf_wire_occupancy_grid_to_cells": (C.c_int, [C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_double, C.c_double,
+                                                   C.c_double, C.c_int, C.POINTER(C.c_int32), _ip, _ip,
+                                                   C.POINTER(C.c_float), _dp]),
+    "bpf_wire_decimate_cloud": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "bpf_wire_samples_to_pose_array": (C.c_int, [_dp, C.c_int, _dp]),
     "bpf_map3d_set": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, _ip, _ip,
                                 C.c_double, C.c_double]),
     "bpf_cloud_init": (C.c_int, [_vp, C.c_int]),

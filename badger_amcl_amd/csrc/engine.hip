@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <queue>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -233,6 +234,13 @@ struct bpf_engine
   SampleSet scratch;  // Seam A host-buffer path
   SampleSet snap;
   int snap_count = 0, snap_leaf = 0, snap_bins = 0;
+
+  // ---- cluster statistics (host, lazy)
+  std::vector<bpf_cluster> clusters;
+  double set_mean[3] = { 0, 0, 0 }, set_cov[5] = { 0, 0, 0, 0, 0 };
+  long long stats_epoch = -1;   // value of set_epoch the statistics were computed for
+  long long set_epoch = 0;      // bumped whenever the current set's poses / weights change
+  bool hist_matches_set = false;
 
   // ---- profiling
   bool profiling = false;
@@ -1630,6 +1638,8 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
     return rc;
   e->sample_count = sample_count;
   e->tile_sums_n = -1;
+  e->set_epoch++;
+  e->hist_matches_set = leaf_count < 0;
   // initWith*: w_slow_ = w_fast_ = 0, converged = false (particle_filter.cpp:127,157,164-168)
   HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
   e->converged = 0;
@@ -1709,6 +1719,8 @@ int bpf_pf_restore(bpf_engine* e)
   e->leaf_count = e->snap_leaf;
   e->bin_count = e->snap_bins;
   e->tile_sums_n = -1;
+  e->set_epoch++;
+  e->hist_matches_set = false;
   return BPF_OK;
 }
 
@@ -1717,6 +1729,7 @@ int bpf_pf_fill_weights(bpf_engine* e, double weight)
   if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
   e->tile_sums_n = -1;
+  e->set_epoch++;
   HIPCHK(e, hipSetDevice(e->device));
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(e->sample_count, 256)), dim3(256), 0, e->stream,
                      e->sets[e->cur].w.p, weight, e->sample_count);
@@ -1771,6 +1784,7 @@ int bpf_pf_update_sensor_planar(bpf_engine* e, const double* ranges, const doubl
     HIPCHK(e, hipGetLastError());
   }
   e->last_status = BPF_OK;
+  e->set_epoch++;
   return BPF_OK;
 }
 
@@ -1837,6 +1851,8 @@ int bpf_pf_update_resample(bpf_engine* e)
   }
   // miss flag was copied? read it with the next fetch; report asynchronously via last_status
   e->last_status = BPF_OK;
+  e->set_epoch++;
+  e->hist_matches_set = true;
   return BPF_OK;
 }
 
@@ -1865,6 +1881,328 @@ int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out)
   out->last_status = e->last_status;
   out->resample_windows = e->resample_windows;
   out->evals = e->evals_last;
+  return BPF_OK;
+}
+
+// ---------------------------------------------------------------------- cluster statistics
+namespace
+{
+// particle_filter.cpp:505-636 on a host copy of the current set, in index order
+int compute_cluster_stats(bpf_engine* e)
+{
+  if (e->stats_epoch == e->set_epoch)
+    return BPF_OK;
+  const int n = e->sample_count;
+  std::vector<double> s((size_t)n * 4);
+  int got = 0;
+  int rc = bpf_pf_get_samples(e, s.data(), n, &got);
+  if (rc != BPF_OK)
+    return rc;
+  if (!e->hist_matches_set)
+  {
+    // the histogram tree of this set is not at hand (set loaded with an explicit leaf count, or
+    // restored): rebuild it the way initWith* / the resamplers do, by inserting every pose in order
+    e->hist.clear();
+    for (int i = 0; i < n; ++i)
+    {
+      int key[3];
+      host_pose_key(s[4 * i], s[4 * i + 1], s[4 * i + 2], key);
+      e->hist.insert(key[0], key[1], key[2]);
+    }
+    e->hist_matches_set = true;
+  }
+  e->hist.label_components();
+  const int max_clusters = e->max_samples;  // cluster_max_count (particle_filter.cpp:84)
+  struct Acc
+  {
+    int count = 0;
+    double weight = 0, m[4] = { 0, 0, 0, 0 }, c[4] = { 0, 0, 0, 0 };
+  };
+  std::vector<Acc> acc;
+  int cluster_count = 0;
+  double weight = 0.0, m[4] = { 0, 0, 0, 0 }, c[4] = { 0, 0, 0, 0 };
+  for (int i = 0; i < n; ++i)
+  {
+    const double* p = &s[4 * i];
+    const double w = p[3];
+    int key[3];
+    host_pose_key(p[0], p[1], p[2], key);
+    const int node = e->hist.find(key[0], key[1], key[2]);
+    const int cidx = node < 0 ? -1 : e->hist.label_of(node);
+    if (cidx < 0 || cidx >= max_clusters)
+      continue;  // :574-576
+    if (cidx + 1 > cluster_count)
+      cluster_count = cidx + 1;
+    if ((int)acc.size() < cluster_count)
+      acc.resize(cluster_count);
+    Acc& a = acc[cidx];
+    a.count += 1;
+    a.weight += w;
+    a.m[0] += w * p[0];
+    a.m[1] += w * p[1];
+    a.m[2] += w * std::cos(p[2]);
+    a.m[3] += w * std::sin(p[2]);
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 2; ++k)
+        a.c[2 * j + k] += w * p[j] * p[k];
+    weight += w;
+    m[0] += w * p[0];
+    m[1] += w * p[1];
+    m[2] += w * std::cos(p[2]);
+    m[3] += w * std::sin(p[2]);
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 2; ++k)
+        c[2 * j + k] += w * p[j] * p[k];
+  }
+  e->clusters.assign((size_t)cluster_count, bpf_cluster{});
+  for (int k = 0; k < cluster_count; ++k)
+  {
+    const Acc& a = acc[k];
+    bpf_cluster& o = e->clusters[k];
+    o.count = a.count;
+    o.weight = a.weight;
+    o.mean[0] = a.m[0] / a.weight;
+    o.mean[1] = a.m[1] / a.weight;
+    o.mean[2] = std::atan2(a.m[3], a.m[2]);
+    for (int j = 0; j < 2; ++j)
+      for (int q = 0; q < 2; ++q)
+        o.cov[2 * j + q] = a.c[2 * j + q] / a.weight - o.mean[j] * o.mean[q];
+    o.cov[4] = -2 * std::log(std::sqrt(a.m[2] * a.m[2] + a.m[3] * a.m[3]));
+  }
+  e->set_mean[0] = m[0] / weight;
+  e->set_mean[1] = m[1] / weight;
+  e->set_mean[2] = std::atan2(m[3], m[2]);
+  for (int j = 0; j < 2; ++j)
+    for (int q = 0; q < 2; ++q)
+      e->set_cov[2 * j + q] = c[2 * j + q] / weight - e->set_mean[j] * e->set_mean[q];
+  e->set_cov[4] = -2 * std::log(std::sqrt(m[2] * m[2] + m[3] * m[3]));
+  e->stats_epoch = e->set_epoch;
+  return BPF_OK;
+}
+}  // namespace
+
+int bpf_pf_compute_cluster_stats(bpf_engine* e, int* cluster_count_out, double set_mean[3], double set_cov[5])
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  int rc = compute_cluster_stats(e);
+  if (rc != BPF_OK)
+    return rc;
+  if (cluster_count_out)
+    *cluster_count_out = (int)e->clusters.size();
+  if (set_mean)
+    std::memcpy(set_mean, e->set_mean, sizeof(e->set_mean));
+  if (set_cov)
+    std::memcpy(set_cov, e->set_cov, sizeof(e->set_cov));
+  return BPF_OK;
+}
+
+int bpf_pf_get_cluster(bpf_engine* e, int cidx, bpf_cluster* out)
+{
+  if (!e || !out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  int rc = compute_cluster_stats(e);
+  if (rc != BPF_OK)
+    return rc;
+  if (cidx < 0 || cidx >= (int)e->clusters.size())
+    return BPF_ERR_INVALID_ARGUMENT;  // getClusterStats returns false (particle_filter.cpp:642-643)
+  *out = e->clusters[cidx];
+  return BPF_OK;
+}
+
+int bpf_pf_get_max_weight_pose(bpf_engine* e, double* max_weight, double pose[3])
+{
+  if (!e || !max_weight || !pose)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  int rc = compute_cluster_stats(e);
+  if (rc != BPF_OK)
+    return rc;
+  double best = 0.0;
+  int hyp = -1;
+  for (size_t k = 0; k < e->clusters.size(); ++k)
+    if (e->clusters[k].weight > best)  // node_2d.cpp:608-612
+    {
+      best = e->clusters[k].weight;
+      hyp = (int)k;
+    }
+  *max_weight = best;
+  if (hyp >= 0)
+    std::memcpy(pose, e->clusters[hyp].mean, 3 * sizeof(double));
+  return BPF_OK;
+}
+
+// ---------------------------------------------------------------------- reference brushfire (host)
+int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_map)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
+  if (max_dist == 0.0)
+    return BPF_OK;  // occupancy_map.cpp:141-145
+  HIPCHK(e, hipSetDevice(e->device));
+  const int sx = e->map.size_x, sy = e->map.size_y;
+  const double res = e->map.resolution;
+  const int radius = (int)std::floor(max_dist / res);
+  std::vector<float> lut((size_t)sx * sy);
+  std::vector<bool> marked((size_t)sx * sy, false);
+  struct Cell
+  {
+    int i, j, si, sj;
+    const float* lut;
+    int sx;
+    bool operator<(const Cell& b) const { return lut[i + (size_t)j * sx] > lut[b.i + (size_t)b.j * sx]; }
+  };
+  std::priority_queue<Cell> q;
+  for (int i = 0; i < sx; ++i)
+    for (int j = 0; j < sy; ++j)
+    {
+      const size_t idx = i + (size_t)j * sx;
+      if (e->h_cells8[idx] == 1)
+      {
+        lut[idx] = 0.0f;
+        marked[idx] = true;
+        q.push(Cell{ i, j, i, j, lut.data(), sx });
+      }
+      else
+        lut[idx] = (float)max_dist;
+    }
+  auto visit = [&](int i, int j, const Cell& cur) {
+    const size_t idx = i + (size_t)j * sx;
+    if (marked[idx])
+      return;
+    const int di = std::abs(i - cur.si), dj = std::abs(j - cur.sj);
+    const double d = std::sqrt((double)(di * di + dj * dj));
+    if (d <= radius)
+    {
+      lut[idx] = (float)(d * res);
+      q.push(Cell{ i, j, cur.si, cur.sj, lut.data(), sx });
+      marked[idx] = true;
+    }
+  };
+  while (!q.empty())
+  {
+    const Cell cur = q.top();
+    if (cur.i > 0)
+      visit(cur.i - 1, cur.j, cur);
+    if (cur.j > 0)
+      visit(cur.i, cur.j - 1, cur);
+    if (cur.i < sx - 1)
+      visit(cur.i + 1, cur.j, cur);
+    if (cur.j < sy - 1)
+      visit(cur.i, cur.j + 1, cur);
+    q.pop();
+  }
+  e->map.max_dist = max_dist;
+  return encode_lut(e, lut.data());
+}
+
+// ---------------------------------------------------------------------- wire formats
+int bpf_wire_laserscan_to_planar(const float* ranges, int n, float msg_range_min, float msg_range_max,
+                                 double sensor_min_range, double sensor_max_range, double angle_min,
+                                 double angle_increment, double* ranges_out, double* angles_out, double* range_max_out)
+{
+  if (!ranges || n < 0 || !ranges_out || !angles_out || !range_max_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  // node_2d.cpp:535-543
+  double range_max;
+  if (sensor_max_range > 0.0)
+    range_max = std::min(msg_range_max, static_cast<float>(sensor_max_range));
+  else
+    range_max = msg_range_max;
+  double range_min;
+  if (sensor_min_range > 0.0)
+    range_min = std::max(msg_range_min, static_cast<float>(sensor_min_range));
+  else
+    range_min = msg_range_min;
+  for (int i = 0; i < n; ++i)
+  {
+    // :548-558: short readings become max range; bearing = angle_min + i * increment
+    if (ranges[i] <= range_min)
+      ranges_out[i] = range_max;
+    else
+      ranges_out[i] = ranges[i];
+    angles_out[i] = angle_min + (i * angle_increment);
+  }
+  *range_max_out = range_max;
+  return BPF_OK;
+}
+
+int bpf_wire_occupancy_grid_to_cells(const int8_t* data, int width, int height, double msg_resolution,
+                                     double msg_origin_x, double msg_origin_y, int map_scale_up_factor,
+                                     int32_t* cells_out, int* size_x_out, int* size_y_out, float origin_out[2],
+                                     double* resolution_out)
+{
+  if (!data || width <= 0 || height <= 0 || map_scale_up_factor < 1 || !cells_out || !size_x_out || !size_y_out ||
+      !origin_out || !resolution_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  // node_2d.cpp:267-277
+  const int f = map_scale_up_factor;
+  const double resolution = msg_resolution / f;
+  const int sx = width * f, sy = height * f;
+  const double x_origin = msg_origin_x + (sx / 2) * resolution;
+  const double y_origin = msg_origin_y + (sy / 2) * resolution;
+  origin_out[0] = (float)x_origin;  // pcl::PointXYZ narrows to float
+  origin_out[1] = (float)y_origin;
+  for (int y = 0; y < sy; ++y)
+  {
+    int i = y * sx;
+    const int msg_row = (y / f) * width;
+    for (int x = 0; x < sx; ++x, ++i)
+    {
+      const int8_t v = data[msg_row + x / f];
+      cells_out[i] = (v == 0) ? -1 : (v == 100 ? 1 : 0);  // :285-290
+    }
+  }
+  *size_x_out = sx;
+  *size_y_out = sy;
+  *resolution_out = resolution;
+  return BPF_OK;
+}
+
+int bpf_wire_decimate_cloud(const float* points_xyz, int n_points, int max_beams, float* out_xyz, int capacity)
+{
+  if (!points_xyz || !out_xyz || n_points < 0 || max_beams < 2)
+    return -1;
+  int step = (n_points - 1) / (max_beams - 1);  // node_3d.cpp:471-472
+  step = std::max(step, 1);
+  int k = 0;
+  for (int i = 0; i < n_points; i += step)
+  {
+    if (k >= capacity)
+      return -1;
+    out_xyz[3 * k] = points_xyz[3 * i];
+    out_xyz[3 * k + 1] = points_xyz[3 * i + 1];
+    out_xyz[3 * k + 2] = points_xyz[3 * i + 2];
+    ++k;
+  }
+  return k;
+}
+
+int bpf_wire_samples_to_pose_array(const double* samples, int sample_count, double* poses7_out)
+{
+  if (!samples || !poses7_out || sample_count < 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < sample_count; ++i)
+  {
+    // tf2::Quaternion::setRPY(0, 0, yaw) (third party, tf2 LinearMath): with zero roll and pitch the
+    // products reduce to (0, 0, sin(yaw/2), cos(yaw/2))
+    const double h = samples[4 * i + 2] * 0.5;
+    double* o = &poses7_out[7 * i];
+    o[0] = samples[4 * i];
+    o[1] = samples[4 * i + 1];
+    o[2] = 0.0;
+    o[3] = 0.0;
+    o[4] = 0.0;
+    o[5] = std::sin(h);
+    o[6] = std::cos(h);
+  }
   return BPF_OK;
 }
 

@@ -161,6 +161,13 @@ class OccupancyMap:
         self.max_distance_to_object = float(max_distance_to_object)
         self.lut = None
 
+    def updateDistancesLUTReference(self, max_distance_to_object):
+        """The reference's priority-queue brushfire (occupancy_map.cpp:138-252), bit-identical LUT."""
+        self.upload()
+        self.e.check(self.e.lib.bpf_map2d_build_distances_lut_reference(self.e.h, float(max_distance_to_object)))
+        self.max_distance_to_object = float(max_distance_to_object)
+        self.lut = None
+
     def getDistancesLUT(self):
         out = np.zeros((self.size_y, self.size_x), dtype=np.float32)
         self.e.check(self.e.lib.bpf_map2d_get_distances_lut(self.e.h, out.ctypes.data_as(C.POINTER(C.c_float)),
@@ -259,6 +266,31 @@ class ParticleFilter:
 
     def isConverged(self):
         return bool(self.getState().converged)
+
+    # ---- cluster statistics (particle_filter.cpp:505-660)
+    def computeClusterStats(self):
+        """Returns (cluster_count, set_mean[3], set_cov[5]); cov entries (0,0) (0,1) (1,0) (1,1) (2,2)."""
+        n = C.c_int()
+        mean = np.zeros(3)
+        cov = np.zeros(5)
+        self.e.check(self.e.lib.bpf_pf_compute_cluster_stats(self.e.h, C.byref(n), _dp(mean), _dp(cov)))
+        return n.value, mean, cov
+
+    def getClusterStats(self, cidx):
+        """ParticleFilter::getClusterStats: (weight, mean) or None when cidx is past the last cluster."""
+        c = _lib.Cluster()
+        rc = self.e.lib.bpf_pf_get_cluster(self.e.h, int(cidx), C.byref(c))
+        if rc == 1:  # BPF_ERR_INVALID_ARGUMENT
+            return None
+        self.e.check(rc)
+        return c.weight, np.array(c.mean[:]), c.count, np.array(c.cov[:])
+
+    def getMaxWeightPose(self):
+        """Node2D::getMaxWeightPose (node_2d.cpp:588-617): (max_weight, pose)."""
+        w = C.c_double()
+        pose = np.zeros(3)
+        self.e.check(self.e.lib.bpf_pf_get_max_weight_pose(self.e.h, C.byref(w), _dp(pose)))
+        return w.value, pose
 
 
 class PlanarScanner:

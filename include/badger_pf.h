@@ -90,6 +90,10 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
  * host LUT to bpf_map2d_set when parity with it matters. */
 int bpf_map2d_build_distances_lut(bpf_engine* e, double max_dist);
 int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity);
+/* OccupancyMap::updateDistancesLUT exactly as the reference builds it (occupancy_map.cpp:138-252):
+ * priority-queue brushfire on the host (std::priority_queue, so tie order matches a libstdc++
+ * build of the reference), ~2 s for a 2000 x 2000 map.  Parity mode for SURVEY 8(f) next-3. */
+int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist);
 
 /* ------------------------------------------------------------------ planar scanner
  * PlanarScanner::{init, setModel*, setMapFactors, setPlanarScannerPose}
@@ -183,6 +187,26 @@ typedef struct
 } bpf_pf_state;
 int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out);
 
+/* ------------------------------------------------------------------ cluster statistics
+ * ParticleFilter::computeClusterStatsForSet (particle_filter.cpp:505-636) with PFKDTree::cluster
+ * (pf_kdtree.cpp:58-90,169-194), and what Node2D::getMaxWeightPose (node_2d.cpp:588-617) reads.
+ * Evaluated on the host, lazily (first query after the set changed), from a copy of the resident
+ * set and the engine's histogram tree, in the reference's serial order -- bit-exact, and only a few
+ * thousand samples in the tracking regime. */
+typedef struct
+{
+  int count;        /* PFCluster::count */
+  double weight;    /* PFCluster::weight */
+  double mean[3];   /* PFCluster::mean */
+  double cov[5];    /* PFCluster::cov at (0,0) (0,1) (1,0) (1,1) (2,2); the other entries are unset in the reference */
+} bpf_cluster;
+/* cluster_count = PFSampleSet::cluster_count; set_mean / set_cov (nullable) = PFSampleSet::mean / cov */
+int bpf_pf_compute_cluster_stats(bpf_engine* e, int* cluster_count_out, double set_mean[3], double set_cov[5]);
+/* ParticleFilter::getClusterStats(cidx, &weight, &mean): returns BPF_ERR_INVALID_ARGUMENT for cidx >= cluster_count */
+int bpf_pf_get_cluster(bpf_engine* e, int cidx, bpf_cluster* out);
+/* Node2D::getMaxWeightPose: the heaviest cluster's weight and mean (weight 0 when there is none) */
+int bpf_pf_get_max_weight_pose(bpf_engine* e, double* max_weight, double pose[3]);
+
 /* ------------------------------------------------------------------ 3-D map + point cloud
  * OctoMap LUT state (include/amcl/map/octomap.h:96-110): pose_indices_, distance_ratios_,
  * cropped_min_cells_, cropped_max_cells_, resolution_, max_distance_to_object_. */
@@ -259,6 +283,28 @@ int bpf_kld_reset(bpf_engine* e);
 int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys, int first_draw_index,
                  int* stop_count_out);
 int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out);
+
+/* ------------------------------------------------------------------ wire formats
+ * The callers' data shaping, as plain host functions (no engine needed). */
+/* Node2D::updateLatestScanData (node_2d.cpp:531-560): float LaserScan ranges -> PlanarData.
+ * sensor_min_range / sensor_max_range <= 0 mean "not set".  ranges_out / angles_out hold n doubles. */
+int bpf_wire_laserscan_to_planar(const float* ranges, int n, float msg_range_min, float msg_range_max,
+                                 double sensor_min_range, double sensor_max_range, double angle_min,
+                                 double angle_increment, double* ranges_out, double* angles_out,
+                                 double* range_max_out);
+/* Node2D::convertMap (node_2d.cpp:265-295): nav_msgs/OccupancyGrid -> tri-state cells with integer
+ * up-scaling and the centre origin (narrowed to float like pcl::PointXYZ).  cells_out holds
+ * (width*scale) * (height*scale) int32. */
+int bpf_wire_occupancy_grid_to_cells(const int8_t* data, int width, int height, double msg_resolution,
+                                     double msg_origin_x, double msg_origin_y, int map_scale_up_factor,
+                                     int32_t* cells_out, int* size_x_out, int* size_y_out, float origin_out[2],
+                                     double* resolution_out);
+/* Node3D::updateLatestScanData (node_3d.cpp:467-480): keep every step-th point, step = max((n-1)/(max_beams-1), 1).
+ * Returns the number of points written (xyz triples); capacity in points. */
+int bpf_wire_decimate_cloud(const float* points_xyz, int n_points, int max_beams, float* out_xyz, int capacity);
+/* Node::publishParticleCloud (node.cpp:335-357): samples -> PoseArray entries {x, y, 0, qx, qy, qz, qw}
+ * with q = setRPY(0, 0, theta). */
+int bpf_wire_samples_to_pose_array(const double* samples, int sample_count, double* poses7_out);
 
 /* ------------------------------------------------------------------ measurement */
 enum

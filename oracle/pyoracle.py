@@ -280,6 +280,18 @@ class KDTree:
         a = np.asarray(pose, dtype=np.float64)
         return lib().orc_kdtree_get_cluster(self.h, _dp(a))
 
+    def cluster_stats(self, samples, max_clusters):
+        """computeClusterStatsForSet on this tree: dict(count, weight, mean, cov, set_mean, set_cov)."""
+        s = np.ascontiguousarray(samples, dtype=np.float64)
+        cnt = np.zeros(max_clusters, dtype=np.int32)
+        w = np.zeros(max_clusters)
+        mean = np.zeros((max_clusters, 3))
+        cov = np.zeros((max_clusters, 5))
+        sm, sc = np.zeros(3), np.zeros(5)
+        k = lib().orc_pf_cluster_stats(self.h, _dp(s), s.shape[0], max_clusters, _ip(cnt), _dp(w), _dp(mean),
+                                       _dp(cov), _dp(sm), _dp(sc))
+        return dict(n=k, count=cnt[:k], weight=w[:k], mean=mean[:k], cov=cov[:k], set_mean=sm, set_cov=sc)
+
 
 # ----------------------------------------------------------------- particle filter
 class ParticleFilter:
