@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.environ.get("BPF_LIB") or os.path.join(HERE, "libbadger_pf_hip.so")  # BPF_LIB: experiment builds
 
-BPF_K_COUNT = 8
+BPF_K_COUNT = 9
 
 
 class PFState(C.Structure):
@@ -66,6 +66,9 @@ SIGNATURES = {
     "bpf_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "bpf_get_cells_walked": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
     "bpf_pf_get_state": (C.c_int, [_vp, C.POINTER(PFState)]),
+    "bpf_odom_set_model": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "bpf_pf_update_action": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "bpf_shard_update_action": (C.c_int, [_vp, _dp, _dp, _dp, C.c_longlong, C.c_longlong]),
     "bpf_pf_compute_cluster_stats": (C.c_int, [_vp, _ip, _dp, _dp]),
     "bpf_pf_get_cluster": (C.c_int, [_vp, C.c_int, C.POINTER(Cluster)]),
     "bpf_pf_get_max_weight_pose": (C.c_int, [_vp, _dp, _dp]),

@@ -17,6 +17,7 @@
 #include "device_types.hpp"
 #include "kdhist.hpp"
 #include "kernels_cloud.hpp"
+#include "kernels_motion.hpp"
 #include "kernels_pf.hpp"
 #include "kernels_score.hpp"
 #include "kernels_window.hpp"
@@ -234,6 +235,15 @@ struct bpf_engine
   SampleSet scratch;  // Seam A host-buffer path
   SampleSet snap;
   int snap_count = 0, snap_leaf = 0, snap_bins = 0;
+
+  // ---- motion model
+  int odom_model = BPF_ODOM_MODEL_DIFF;
+  double odom_alpha[5] = { 0, 0, 0, 0, 0 };
+  bool odom_configured = false;
+  DevBuf<int> d_motion_counts;
+  DevBuf<long long> d_motion_offsets, d_motion_result;
+  DevBuf<double> d_gauss;
+  PinnedBuf<long long> h_motion_result;
 
   // ---- cluster statistics (host, lazy)
   std::vector<bpf_cluster> clusters;
@@ -1882,6 +1892,180 @@ int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out)
   out->resample_windows = e->resample_windows;
   out->evals = e->evals_last;
   return BPF_OK;
+}
+
+// ---------------------------------------------------------------------- motion update
+namespace
+{
+double odom_angle_diff(double a, double b)
+{
+  // Odom::angleDiff (odom.cpp:308-311) = angles::shortest_angular_distance(b, a) = normalize_angle(a - b);
+  // angles::normalize_angle in its Noetic form (third party)
+  const double r = std::fmod((a - b) + M_PI, 2.0 * M_PI);
+  return (r <= 0.0) ? r + M_PI : r - M_PI;
+}
+
+// the loop-invariant part of Odom::updateAction, with the host libm like the reference
+MotionModelDev motion_constants(const bpf_engine* e, const double pose[3], const double delta[3],
+                                const double absolute_motion[3])
+{
+  MotionModelDev M{};
+  M.model = e->odom_model;
+  const double a1 = e->odom_alpha[0], a2 = e->odom_alpha[1], a3 = e->odom_alpha[2], a4 = e->odom_alpha[3],
+               a5 = e->odom_alpha[4];
+  const double old_th = pose[2] - delta[2];  // odom.cpp:82-85
+  const double delta_trans = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1]);
+  M.delta_trans = delta_trans;
+  M.delta_rot = delta[2];
+  M.half_rot = delta[2] / 2;
+  M.bearing0 = odom_angle_diff(std::atan2(delta[1], delta[0]), old_th);
+  if (M.model == BPF_ODOM_MODEL_OMNI || M.model == BPF_ODOM_MODEL_OMNI_CORRECTED)
+  {
+    const double delta_rot = delta[2];
+    M.sd[0] = a3 * (delta_trans * delta_trans) + a1 * (delta_rot * delta_rot);  // :101-106 / :181-186
+    M.sd[1] = a4 * (delta_rot * delta_rot) + a2 * (delta_trans * delta_trans);
+    M.sd[2] = a1 * (delta_rot * delta_rot) + a5 * (delta_trans * delta_trans);
+    if (M.model == BPF_ODOM_MODEL_OMNI_CORRECTED)
+      for (double& v : M.sd)
+        v = std::sqrt(v);
+  }
+  else if (M.model == BPF_ODOM_MODEL_DIFF || M.model == BPF_ODOM_MODEL_DIFF_CORRECTED)
+  {
+    M.rot1 = (delta_trans < 0.01) ? 0.0 : M.bearing0;  // :135-138 / :213-216
+    M.rot2 = odom_angle_diff(delta[2], M.rot1);
+    const double r1a = std::fabs(odom_angle_diff(M.rot1, 0.0)), r1b = std::fabs(odom_angle_diff(M.rot1, M_PI));
+    const double r2a = std::fabs(odom_angle_diff(M.rot2, 0.0)), r2b = std::fabs(odom_angle_diff(M.rot2, M_PI));
+    const double n1 = std::min(r1a, r1b), n2 = std::min(r2a, r2b);
+    M.sd[0] = a1 * n1 * n1 + a2 * delta_trans * delta_trans;  // :156-162 / :233-243
+    M.sd[1] = a3 * delta_trans * delta_trans + a4 * n1 * n1 + a4 * n2 * n2;
+    M.sd[2] = a1 * n2 * n2 + a2 * delta_trans * delta_trans;
+    if (M.model == BPF_ODOM_MODEL_DIFF_CORRECTED)
+      for (double& v : M.sd)
+        v = std::sqrt(v);
+  }
+  else
+  {
+    const double at2 = absolute_motion[0] * absolute_motion[0];  // :264-274
+    const double as2 = absolute_motion[1] * absolute_motion[1];
+    const double ar2 = absolute_motion[2] * absolute_motion[2];
+    const double rot_sd = std::sqrt(a1 * ar2 + a2 * at2);
+    const double trans_sd = std::sqrt(a3 * at2 + a4 * ar2);
+    const double strafe_sd = std::sqrt(a4 * ar2 + a5 * as2);
+    M.sd[0] = trans_sd;  // draw order :289-291
+    M.sd[1] = strafe_sd;
+    M.sd[2] = rot_sd;
+  }
+  return M;
+}
+
+int update_action(bpf_engine* e, const double pose[3], const double delta[3], const double absolute_motion[3],
+                  long long global_first, long long global_count)
+{
+  const int n = e->sample_count;
+  if (global_first < 0 || global_first + n > global_count)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "shard range outside the global set");
+  HIPCHK(e, hipSetDevice(e->device));
+  const MotionModelDev M = motion_constants(e, pose, delta, absolute_motion);
+  const long long need = 3 * global_count;
+  // attempts are accepted with probability pi/4; 6 sigma of slack, doubled on the (never yet seen) shortfall
+  long long attempts = (long long)std::ceil((double)need / 0.7853981633974483 + 6.0 * std::sqrt((double)need)) + 64;
+  HIPCHK(e, e->d_motion_result.reserve(4));
+  HIPCHK(e, e->h_motion_result.reserve(4));
+  HIPCHK(e, e->d_gauss.reserve((size_t)3 * n));
+  SampleSet& src = e->sets[e->cur];
+  SampleSet& dst = e->sets[e->cur ^ 1];
+  long long zero_at = kNoZero;
+  for (int round = 0; round < 8; ++round)
+  {
+    const int tiles = (int)((attempts + kMotionTile - 1) / kMotionTile);
+    HIPCHK(e, e->d_motion_counts.reserve((size_t)tiles));
+    HIPCHK(e, e->d_motion_offsets.reserve((size_t)tiles + 1));
+    MotionRngArgs A{};
+    A.rng_state = e->rng;
+    A.zero_at = zero_at;
+    A.n_attempts = attempts;
+    A.need_total = need;
+    A.gauss_first = 3 * global_first;
+    A.gauss_count = 3ll * n;
+    A.tile_counts = e->d_motion_counts.p;
+    A.tile_offsets = e->d_motion_offsets.p;
+    A.gauss = e->d_gauss.p;
+    A.result = e->d_motion_result.p;
+    for (int k = 0; k < 3; ++k)
+      A.sd[k] = M.sd[k];
+    A.jump = e->jump;
+    {
+      ProfScope ps(e, BPF_K_MOTION);
+      HIPCHK(e, hipMemsetAsync(e->d_motion_result.p, 0, 4 * sizeof(long long), e->stream));
+      hipLaunchKernelGGL(k_motion_count, dim3(tiles), dim3(256), 0, e->stream, A);
+      hipLaunchKernelGGL(k_motion_offsets, dim3(1), dim3(1024), 0, e->stream, A, tiles);
+      hipLaunchKernelGGL(k_motion_gauss, dim3(tiles), dim3(256), 0, e->stream, A);
+      // optimistic: poses go to the other set, which becomes current only once the pass is known good
+      hipLaunchKernelGGL(k_motion_apply, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, src.dev(), dst.dev(), n,
+                         M, (const double*)e->d_gauss.p);
+      HIPCHK(e, hipGetLastError());
+    }
+    HIPCHK(e, hipMemcpyAsync(e->h_motion_result.p, e->d_motion_result.p, 4 * sizeof(long long), hipMemcpyDeviceToHost,
+                             e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const long long consumed = e->h_motion_result.p[0], zero_seen = e->h_motion_result.p[1],
+                    accepted = e->h_motion_result.p[2];
+    if (zero_at == kNoZero && zero_seen > 0)
+    {
+      zero_at = zero_seen;  // the stream's one exact 0.0 lies in the window: re-run with it skipped
+      continue;
+    }
+    if (accepted < need || consumed <= 0)
+    {
+      attempts *= 2;
+      continue;
+    }
+    e->rng = lcg_skip_host(e->rng, (uint64_t)consumed, e->jump);
+    e->cur ^= 1;
+    e->tile_sums_n = -1;
+    e->fused_partials = 0;
+    e->set_epoch++;
+    e->hist_matches_set = false;
+    return BPF_OK;
+  }
+  return e->fail(BPF_ERR_HIP, "motion update: Gaussian stream did not fill (internal error)");
+}
+}  // namespace
+
+int bpf_odom_set_model(bpf_engine* e, int model_type, double alpha1, double alpha2, double alpha3, double alpha4,
+                       double alpha5)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (model_type < BPF_ODOM_MODEL_DIFF || model_type > BPF_ODOM_MODEL_GAUSSIAN)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown odom model type");
+  e->odom_model = model_type;
+  e->odom_alpha[0] = alpha1;
+  e->odom_alpha[1] = alpha2;
+  e->odom_alpha[2] = alpha3;
+  e->odom_alpha[3] = alpha4;
+  e->odom_alpha[4] = alpha5;
+  e->odom_configured = true;
+  return BPF_OK;
+}
+
+int bpf_pf_update_action(bpf_engine* e, const double pose[3], const double delta[3], const double absolute_motion[3])
+{
+  if (!e || !pose || !delta || !absolute_motion)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf || !e->odom_configured)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create and bpf_odom_set_model first");
+  return update_action(e, pose, delta, absolute_motion, 0, e->sample_count);
+}
+
+int bpf_shard_update_action(bpf_engine* e, const double pose[3], const double delta[3],
+                            const double absolute_motion[3], long long global_first, long long global_count)
+{
+  if (!e || !pose || !delta || !absolute_motion)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf || !e->odom_configured)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create and bpf_odom_set_model first");
+  return update_action(e, pose, delta, absolute_motion, global_first, global_count);
 }
 
 // ---------------------------------------------------------------------- cluster statistics

@@ -81,7 +81,7 @@ class Engine:
     def profile_get(self):
         p = _lib.Profile()
         self.check(self.lib.bpf_profile_get(self.h, C.byref(p)))
-        names = ["score", "reduce", "normalize", "cdf", "draw", "finalize", "score_window", "score_aux"]
+        names = ["score", "reduce", "normalize", "cdf", "draw", "finalize", "score_window", "score_aux", "motion"]
         return {n: {"ms": p.ms[i], "launches": p.launches[i]} for i, n in enumerate(names)}
 
     def set_option(self, option, value):
@@ -291,6 +291,41 @@ class ParticleFilter:
         pose = np.zeros(3)
         self.e.check(self.e.lib.bpf_pf_get_max_weight_pose(self.e.h, C.byref(w), _dp(pose)))
         return w.value, pose
+
+
+ODOM_MODEL_DIFF, ODOM_MODEL_OMNI, ODOM_MODEL_DIFF_CORRECTED, ODOM_MODEL_OMNI_CORRECTED, ODOM_MODEL_GAUSSIAN = range(5)
+
+
+class OdomData:
+    """include/amcl/sensors/odom.h:43-52."""
+
+    def __init__(self, pose, delta, absolute_motion=None):
+        self.pose = np.ascontiguousarray(pose, dtype=np.float64)
+        self.delta = np.ascontiguousarray(delta, dtype=np.float64)
+        # Node::updateOdom passes the delta when the odometry integrator is off (node.cpp:1083-1087)
+        self.absolute_motion = np.ascontiguousarray(delta if absolute_motion is None else absolute_motion,
+                                                    dtype=np.float64)
+
+
+class Odom:
+    """Odom sensor (src/amcl/sensors/odom.cpp): setModel + updateAction on the resident set."""
+
+    def __init__(self, engine):
+        self.e = engine
+
+    def setModel(self, model_type, alpha1, alpha2, alpha3, alpha4, alpha5=0.0):
+        self.e.check(self.e.lib.bpf_odom_set_model(self.e.h, int(model_type), alpha1, alpha2, alpha3, alpha4, alpha5))
+
+    def updateAction(self, pf, data):
+        self.e.check(self.e.lib.bpf_pf_update_action(self.e.h, _dp(data.pose), _dp(data.delta),
+                                                     _dp(data.absolute_motion)))
+        return True
+
+    def updateActionShard(self, data, global_first, global_count):
+        self.e.check(self.e.lib.bpf_shard_update_action(self.e.h, _dp(data.pose), _dp(data.delta),
+                                                        _dp(data.absolute_motion), int(global_first),
+                                                        int(global_count)))
+        return True
 
 
 class PlanarScanner:

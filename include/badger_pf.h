@@ -187,6 +187,31 @@ typedef struct
 } bpf_pf_state;
 int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out);
 
+/* ------------------------------------------------------------------ motion update
+ * Odom::setModel / Odom::updateAction (src/amcl/sensors/odom.cpp:63-301, caller node.cpp:1053-1091)
+ * on the resident set: 3 PDFGaussian::draw (pdf_gaussian.cpp:77-97) per particle from the filter's
+ * drand48 stream, consumed in the reference's order (particle by particle, rejected attempts and
+ * r == 0 re-draws included), so the state left for the resampler is exact.  Poses agree with a
+ * libm build of the reference to a few ulp (device log / sin / cos). */
+enum
+{
+  BPF_ODOM_MODEL_DIFF = 0,            /* OdomModelType, include/amcl/sensors/odom.h:33-40 */
+  BPF_ODOM_MODEL_OMNI = 1,
+  BPF_ODOM_MODEL_DIFF_CORRECTED = 2,
+  BPF_ODOM_MODEL_OMNI_CORRECTED = 3,
+  BPF_ODOM_MODEL_GAUSSIAN = 4
+};
+int bpf_odom_set_model(bpf_engine* e, int model_type, double alpha1, double alpha2, double alpha3,
+                       double alpha4, double alpha5);
+/* OdomData: pose, delta, absolute_motion (odom.h:43-52) */
+int bpf_pf_update_action(bpf_engine* e, const double pose[3], const double delta[3],
+                         const double absolute_motion[3]);
+/* the same for one shard of a filter spread over several engines: this engine holds particles
+ * [global_first, global_first + local count) of global_count; every rank passes the same rng state
+ * (bpf_pf_set_rng_state) and ends with the same one. */
+int bpf_shard_update_action(bpf_engine* e, const double pose[3], const double delta[3],
+                            const double absolute_motion[3], long long global_first, long long global_count);
+
 /* ------------------------------------------------------------------ cluster statistics
  * ParticleFilter::computeClusterStatsForSet (particle_filter.cpp:505-636) with PFKDTree::cluster
  * (pf_kdtree.cpp:58-90,169-194), and what Node2D::getMaxWeightPose (node_2d.cpp:588-617) reads.
@@ -317,7 +342,8 @@ enum
   BPF_K_FINALIZE = 5,
   BPF_K_SCORE_WINDOW = 6, /* sensor scoring kernel, LDS-window form (k_score_window) */
   BPF_K_SCORE_AUX = 7,    /* its helpers: k_field_prep, k_field_windows, k_field_finish */
-  BPF_K_COUNT = 8
+  BPF_K_MOTION = 8,       /* k_motion_* */
+  BPF_K_COUNT = 9
 };
 typedef struct
 {

@@ -68,6 +68,111 @@ double orc_normalize_angle(double a)
   return (r <= 0.0) ? r + M_PI : r - M_PI;
 }
 
+/* Odom::angleDiff (odom.cpp:308-311) = angles::shortest_angular_distance(b, a) = normalize_angle(a - b) */
+static double odom_angle_diff(double a, double b)
+{
+  return orc_normalize_angle(a - b);
+}
+
+/* Odom::updateAction, odom.cpp:74-301.  All three draws of a particle come from the one global
+ * drand48 stream in the order written in the reference. */
+void orc_odom_update_action(int model, const double alpha[5], const double pose[3], const double delta[3],
+                            const double absolute_motion[3], double* samples, int n, uint64_t* rng)
+{
+  const double a1 = alpha[0], a2 = alpha[1], a3 = alpha[2], a4 = alpha[3], a5 = alpha[4];
+  const double old_th = pose[2] - delta[2]; /* :82-85, only the heading is used */
+  if (model == 1 || model == 3) /* omni :94-124, omni-corrected :171-201 */
+  {
+    const double delta_trans = sqrt(delta[0] * delta[0] + delta[1] * delta[1]);
+    const double delta_rot = delta[2];
+    double trans_sd = a3 * (delta_trans * delta_trans) + a1 * (delta_rot * delta_rot);
+    double rot_sd = a4 * (delta_rot * delta_rot) + a2 * (delta_trans * delta_trans);
+    double strafe_sd = a1 * (delta_rot * delta_rot) + a5 * (delta_trans * delta_trans);
+    if (model == 3)
+    {
+      trans_sd = sqrt(trans_sd);
+      rot_sd = sqrt(rot_sd);
+      strafe_sd = sqrt(strafe_sd);
+    }
+    for (int i = 0; i < n; i++)
+    {
+      double* p = &samples[4 * i];
+      const double turn_angle = atan2(delta[1], delta[0]);
+      const double bearing = odom_angle_diff(turn_angle, old_th) + p[2];
+      const double cs = cos(bearing), sn = sin(bearing);
+      const double trans_hat = delta_trans + orc_gaussian_draw(rng, trans_sd);
+      const double rot_hat = delta_rot + orc_gaussian_draw(rng, rot_sd);
+      const double strafe_hat = 0 + orc_gaussian_draw(rng, strafe_sd);
+      p[0] += (trans_hat * cs + strafe_hat * sn);
+      p[1] += (trans_hat * sn - strafe_hat * cs);
+      p[2] += rot_hat;
+    }
+  }
+  else if (model == 0 || model == 2) /* diff :125-170, diff-corrected :202-252 */
+  {
+    const double delta_trans = sqrt(delta[0] * delta[0] + delta[1] * delta[1]);
+    double rot1;
+    if (delta_trans < 0.01) /* :135-136 tests sqrt(dy*dy + dx*dx): same two squares, commuted sum */
+      rot1 = 0.0;
+    else
+      rot1 = odom_angle_diff(atan2(delta[1], delta[0]), old_th);
+    const double rot2 = odom_angle_diff(delta[2], rot1);
+    /* std::min(a, b) = (b < a) ? b : a */
+    const double r1a = fabs(odom_angle_diff(rot1, 0.0)), r1b = fabs(odom_angle_diff(rot1, M_PI));
+    const double r2a = fabs(odom_angle_diff(rot2, 0.0)), r2b = fabs(odom_angle_diff(rot2, M_PI));
+    const double rot1_noise = (r1b < r1a) ? r1b : r1a;
+    const double rot2_noise = (r2b < r2a) ? r2b : r2a;
+    double sd1 = a1 * rot1_noise * rot1_noise + a2 * delta_trans * delta_trans;
+    double sd2 = a3 * delta_trans * delta_trans + a4 * rot1_noise * rot1_noise + a4 * rot2_noise * rot2_noise;
+    double sd3 = a1 * rot2_noise * rot2_noise + a2 * delta_trans * delta_trans;
+    if (model == 2)
+    {
+      sd1 = sqrt(sd1);
+      sd2 = sqrt(sd2);
+      sd3 = sqrt(sd3);
+    }
+    for (int i = 0; i < n; i++)
+    {
+      double* p = &samples[4 * i];
+      const double rot1_hat = odom_angle_diff(rot1, orc_gaussian_draw(rng, sd1));
+      const double trans_hat = delta_trans - orc_gaussian_draw(rng, sd2);
+      const double rot2_hat = odom_angle_diff(rot2, orc_gaussian_draw(rng, sd3));
+      p[0] += trans_hat * cos(p[2] + rot1_hat);
+      p[1] += trans_hat * sin(p[2] + rot1_hat);
+      p[2] += rot1_hat + rot2_hat;
+    }
+  }
+  else /* gaussian :253-298 */
+  {
+    const double delta_trans = sqrt(delta[0] * delta[0] + delta[1] * delta[1]);
+    const double delta_rot = delta[2];
+    const double at2 = absolute_motion[0] * absolute_motion[0];
+    const double as2 = absolute_motion[1] * absolute_motion[1];
+    const double ar2 = absolute_motion[2] * absolute_motion[2];
+    const double rot_sd = sqrt(a1 * ar2 + a2 * at2);
+    const double trans_sd = sqrt(a3 * at2 + a4 * ar2);
+    const double strafe_sd = sqrt(a4 * ar2 + a5 * as2);
+    for (int i = 0; i < n; i++)
+    {
+      double* p = &samples[4 * i];
+      const double heading = p[2] + delta[2] / 2;
+      const double ch = cos(heading), sh = sin(heading);
+      const double ndata_angle = atan2(delta[1], delta[0]);
+      const double bearing = odom_angle_diff(ndata_angle, old_th) + p[2];
+      const double cs = cos(bearing), sn = sin(bearing);
+      const double trans_hat = orc_gaussian_draw(rng, trans_sd);
+      const double strafe_hat = orc_gaussian_draw(rng, strafe_sd);
+      const double rot_hat = orc_gaussian_draw(rng, rot_sd);
+      p[0] += (delta_trans * cs);
+      p[1] += (delta_trans * sn);
+      p[2] += delta_rot;
+      p[0] += (trans_hat * ch + strafe_hat * sh);
+      p[1] += (trans_hat * sh - strafe_hat * ch);
+      p[2] += rot_hat;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* 2-D occupancy map                                                           */
 /* ------------------------------------------------------------------------- */

@@ -40,6 +40,10 @@ double orc_drand48(uint64_t* state);
 double orc_gaussian_draw(uint64_t* state, double sigma);
 /* angles::normalize_angle (third-party `angles` package, Noetic form) */
 double orc_normalize_angle(double a);
+/* Odom::updateAction (src/amcl/sensors/odom.cpp:74-301); model = OdomModelType (odom.h:33-40):
+ * 0 diff, 1 omni, 2 diff-corrected, 3 omni-corrected, 4 gaussian.  samples = [n][4]. */
+void orc_odom_update_action(int model, const double alpha[5], const double pose[3], const double delta[3],
+                            const double absolute_motion[3], double* samples, int n, uint64_t* rng);
 
 /* ---- 2-D occupancy map (include/amcl/map/occupancy_map.h:93-102, map.h:48-53) */
 typedef struct

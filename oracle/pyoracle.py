@@ -125,6 +125,8 @@ def lib():
     L.orc_pf_resample_limit.argtypes = [C.POINTER(PF), C.c_int]
     L.orc_pf_update_resample.argtypes = [C.POINTER(PF), dp, C.c_int, C.c_int, dp, ip, C.POINTER(ResampleOut)]
     L.orc_pf_update_converged.argtypes = [C.POINTER(PF), dp, C.c_int, C.POINTER(C.c_float)]
+    L.orc_odom_update_action.argtypes = [C.c_int, dp, dp, dp, dp, dp, C.c_int, C.POINTER(C.c_uint64)]
+    L.orc_odom_update_action.restype = None
     L.orc_pf_cluster_stats.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, ip, dp, dp, dp, dp, dp]
     L.orc_map3d_world_to_map.argtypes = [C.POINTER(Map3D), dp, ip]
     L.orc_map3d_map_to_world.argtypes = [C.c_double, ip, dp]
@@ -291,6 +293,21 @@ class KDTree:
         k = lib().orc_pf_cluster_stats(self.h, _dp(s), s.shape[0], max_clusters, _ip(cnt), _dp(w), _dp(mean),
                                        _dp(cov), _dp(sm), _dp(sc))
         return dict(n=k, count=cnt[:k], weight=w[:k], mean=mean[:k], cov=cov[:k], set_mean=sm, set_cov=sc)
+
+
+# ----------------------------------------------------------------- motion model
+ODOM_MODEL_DIFF, ODOM_MODEL_OMNI, ODOM_MODEL_DIFF_CORRECTED, ODOM_MODEL_OMNI_CORRECTED, ODOM_MODEL_GAUSSIAN = range(5)
+
+
+def odom_update_action(model, alpha, pose, delta, absolute_motion, samples, rng_state):
+    """Odom::updateAction on samples[n,4] in place; returns the drand48 state afterwards."""
+    a = np.asarray(alpha, dtype=np.float64)
+    po, de, am = (np.asarray(v, dtype=np.float64) for v in (pose, delta, absolute_motion))
+    assert samples.dtype == np.float64 and samples.flags.c_contiguous
+    st = C.c_uint64(rng_state)
+    lib().orc_odom_update_action(model, _dp(a), _dp(po), _dp(de), _dp(am), _dp(samples), samples.shape[0],
+                                 C.byref(st))
+    return st.value
 
 
 # ----------------------------------------------------------------- particle filter
