@@ -2,6 +2,8 @@
 contiguous slice of the particle index space, `torch.distributed` (backend "nccl" = RCCL over
 xGMI) carries the three small exchanges the path really has:
 
+  update_action    none: every rank walks the same drand48 stream (attempt compaction over the GLOBAL
+                   Gaussian ranks), materialises the draws of its own index range and ends on the same state
   update_sensor    all-gather of W per-shard weight totals (8 B each)
   update_resample  per candidate-draw window one integer all-reduce(sum) of [6, window] int64 (pose
                    bits + histogram key of every draw; exactly one shard writes each column, the
@@ -111,6 +113,9 @@ class HipShardBackend:
     def set_rng_state(self, s):
         self.pf.setRngState(s)
 
+    def update_action(self, odom, data, global_first, global_count):
+        odom.updateActionShard(data, global_first, global_count)
+
     def max_samples(self):
         return self.pf.max_samples
 
@@ -165,6 +170,11 @@ class ShardedFilter:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
+
+    # ---- motion update (Odom::updateAction): no exchange
+    def update_action(self, odom, data):
+        first = sum(self.counts[:self.rank])
+        self.b.update_action(odom, data, first, self.sample_count)
 
     # ---- Seam A
     def update_sensor(self, data):

@@ -167,6 +167,10 @@ def main():
     ap.add_argument("--model", default="lf", choices=["lf", "gompertz", "beam", "cloud3d"])
     ap.add_argument("--cloud", default="converged", choices=["converged", "spread"])
     ap.add_argument("--resampler", default="multinomial", choices=["multinomial", "systematic"])
+    ap.add_argument("--motion", default="none",
+                    choices=["none", "diff", "omni", "diff-corrected", "omni-corrected", "gaussian"],
+                    help="also run Odom::updateAction on the device inside every step (default: the restored set "
+                         "stands in for the motion update, as the metric is sensor update + resample)")
     ap.add_argument("--particles", type=int, default=None,
                     help="particles per GPU (default 100000; 200000 for cloud3d)")
     ap.add_argument("--beams", type=int, default=1081)
@@ -204,6 +208,14 @@ def main():
     wl["world"] = world
     e, m, sc, pf, data, lut = setup_engine(args, wl, local_rank)
 
+    odom = odata = None
+    if args.motion != "none":
+        import badger_amcl_amd as bpf
+        odom = bpf.Odom(e)
+        odom.setModel(["diff", "omni", "diff-corrected", "omni-corrected", "gaussian"].index(args.motion),
+                      0.05, 0.05, 0.05, 0.05, 0.05)
+        odata = bpf.OdomData((1.0, 2.0, 0.3), (0.02, 0.005, 0.01))
+
     if dist is not None:
         from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
         backend = HipShardBackend(e, sc, pf, torch.device("cuda", local_rank))
@@ -213,11 +225,15 @@ def main():
         def step():
             pf.restore()
             sf.restore(shard_counts)
+            if odom is not None:
+                sf.update_action(odom, odata)
             sf.update_sensor(data)
             sf.update_resample()
     else:
         def step():
             pf.restore()
+            if odom is not None:
+                odom.updateAction(pf, odata)
             sc.updateSensor(pf, data)
             pf.updateResample()
 
@@ -293,7 +309,7 @@ def main():
                              if args.model == "cloud3d" else
                              "2D %s, %d particles/GPU, %d beams, %dx%d map" % (args.model, args.particles, args.beams,
                                                                                args.map_size, args.map_size)),
-                       "cloud": args.cloud, "resampler": args.resampler, "particles_per_gpu": wl["n"],
+                       "cloud": args.cloud, "resampler": args.resampler, "motion": args.motion, "particles_per_gpu": wl["n"],
                        "particles_total": n_total, "resampled_to": int(st.sample_count),
                        "kld_leaf_count": int(st.leaf_count), "parallelism": "particle-shard x%d" % world},
             "roofline": {"bound": "hbm", "kernel": e.score_kernel_name(), "achieved": achieved,

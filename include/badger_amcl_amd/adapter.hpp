@@ -6,6 +6,7 @@
 //   badger_amcl_amd::PlanarScanner     <- PlanarScanner     (include/amcl/sensors/planar_scanner.h:57-168)
 //   badger_amcl_amd::ParticleFilter    <- ParticleFilter    (include/amcl/pf/particle_filter.h:92-184)
 //   badger_amcl_amd::PFSample / PFSampleSet                 (include/amcl/pf/particle_filter.h:41-87)
+//   badger_amcl_amd::OdomData / Odom   <- OdomData / Odom   (include/amcl/sensors/odom.h:43-90)
 //
 // Same method names, argument meaning and return conventions (false / 0.0 on the reference's
 // silent failures); conditions the reference asserts on or hangs in surface as std::runtime_error.
@@ -87,6 +88,14 @@ public:
     lut_ = lut;
     max_dist_ = max_distance_to_object;
     dirty_ = true;
+  }
+  // the reference's own priority-queue brushfire (bit-identical LUT, host, ~2 s per 2000^2 map)
+  void updateDistancesLUTReference(double max_distance_to_object)
+  {
+    upload();
+    e_->check(bpf_map2d_build_distances_lut_reference(e_->get(), max_distance_to_object));
+    max_dist_ = max_distance_to_object;
+    lut_.clear();
   }
   // OccupancyMap::updateDistancesLUT on the device (exact EDT; see badger_pf.h)
   void updateDistancesLUT(double max_distance_to_object)
@@ -184,11 +193,62 @@ public:
     e_->check(bpf_pf_get_state(e_->get(), &st));
     return st;
   }
+  // ParticleFilter::getClusterStats(cidx, &weight, &mean) (particle_filter.cpp:638-649)
+  bool getClusterStats(int cidx, double* weight, std::array<double, 3>* mean)
+  {
+    bpf_cluster c;
+    const int rc = bpf_pf_get_cluster(e_->get(), cidx, &c);
+    if (rc == BPF_ERR_INVALID_ARGUMENT)
+      return false;
+    e_->check(rc);
+    *weight = c.weight;
+    *mean = { c.mean[0], c.mean[1], c.mean[2] };
+    return true;
+  }
+  // Node2D::getMaxWeightPose (node_2d.cpp:588-617)
+  void getMaxWeightPose(double* max_weight_out, std::array<double, 3>* max_pose)
+  {
+    double pose[3] = { 0, 0, 0 };
+    e_->check(bpf_pf_get_max_weight_pose(e_->get(), max_weight_out, pose));
+    *max_pose = { pose[0], pose[1], pose[2] };
+  }
   Engine& engine() { return *e_; }
 
 private:
   std::shared_ptr<Engine> e_;
   int max_samples_;
+};
+
+enum OdomModelType
+{
+  ODOM_MODEL_DIFF = BPF_ODOM_MODEL_DIFF,
+  ODOM_MODEL_OMNI = BPF_ODOM_MODEL_OMNI,
+  ODOM_MODEL_DIFF_CORRECTED = BPF_ODOM_MODEL_DIFF_CORRECTED,
+  ODOM_MODEL_OMNI_CORRECTED = BPF_ODOM_MODEL_OMNI_CORRECTED,
+  ODOM_MODEL_GAUSSIAN = BPF_ODOM_MODEL_GAUSSIAN
+};
+
+struct OdomData
+{
+  std::array<double, 3> pose{}, delta{}, absolute_motion{};
+};
+
+class Odom
+{
+public:
+  explicit Odom(std::shared_ptr<Engine> e) : e_(std::move(e)) {}
+  void setModel(OdomModelType type, double alpha1, double alpha2, double alpha3, double alpha4, double alpha5 = 0)
+  {
+    e_->check(bpf_odom_set_model(e_->get(), type, alpha1, alpha2, alpha3, alpha4, alpha5));
+  }
+  bool updateAction(std::shared_ptr<ParticleFilter>, std::shared_ptr<OdomData> data)
+  {
+    e_->check(bpf_pf_update_action(e_->get(), data->pose.data(), data->delta.data(), data->absolute_motion.data()));
+    return true;
+  }
+
+private:
+  std::shared_ptr<Engine> e_;
 };
 
 class PlanarScanner

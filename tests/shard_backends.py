@@ -155,6 +155,19 @@ class OracleShardBackend:
             C.POINTER(C.c_double)), m, C.byref(pct))
         self.pct = pct.value
 
+    def update_action(self, odom, data, global_first, global_count):
+        """odom = (model, alpha); data = (pose, delta, absolute_motion).  The serial oracle reaches this
+        shard's place in the stream by running (and discarding) the draws of the particles before it."""
+        model, alpha = odom
+        pose, delta, absm = data
+        st = self.pfh.pf.rng
+        before = np.zeros((global_first, 4))
+        st = self.orc.odom_update_action(model, alpha, pose, delta, absm, before, st)
+        st = self.orc.odom_update_action(model, alpha, pose, delta, absm, self.samples, st)
+        after = np.zeros((global_count - global_first - self.samples.shape[0], 4))
+        st = self.orc.odom_update_action(model, alpha, pose, delta, absm, after, st)
+        self.pfh.pf.rng = st
+
     def skip(self, state, n):
         return lcg_skip(state, n)
 

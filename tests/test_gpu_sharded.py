@@ -21,6 +21,10 @@ def _free_port():
     return p
 
 
+ODOM = (2, 0.05, 0.04, 0.03, 0.02, 0.0)                         # diff-corrected
+ODATA = ((1.0, 2.0, 0.3), (0.03, -0.01, 0.02), (0.03, 0.01, 0.02))  # pose, delta, absolute motion
+
+
 def _scenario():
     from oracle import pyoracle as orc
     from scenario import Scenario
@@ -49,8 +53,11 @@ def _worker(rank, world, port, out_dir):
     m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
     b = HipShardBackend(e, scn, pf, torch.device("cuda", 0))
     sf = ShardedFilter(b, dist, first_window=1024)
+    od = bpf.Odom(e)
+    od.setModel(*ODOM)
     recs = []
     for cycle in range(2):
+        sf.update_action(od, bpf.OdomData(*ODATA))
         sf.update_sensor(data)
         w_after = pf.getCurrentSet().samples.copy()
         sf.update_resample()
@@ -76,7 +83,10 @@ def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path):
     n = sc.samples.shape[0]
     e = bpf.Engine(0)
     m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    od = bpf.Odom(e)
+    od.setModel(*ODOM)
     for cycle in range(2):
+        od.updateAction(pf, bpf.OdomData(*ODATA))
         scn.updateSensor(pf, data)
         w_ref = pf.getCurrentSet().samples[:, 3].copy()
         pf.updateResample()

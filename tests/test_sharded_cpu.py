@@ -14,6 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+ODOM = (2, (0.05, 0.04, 0.03, 0.02, 0.0))                       # diff-corrected
+ODATA = ((1.0, 2.0, 0.3), (0.03, -0.01, 0.02), (0.03, 0.01, 0.02))  # pose, delta, absolute motion
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -45,6 +49,7 @@ def _worker(rank, world, port, out_dir, cloud_split):
     data = (sc.ranges, sc.angles, sc.range_max)
     records = []
     for cycle in range(2):
+        sf.update_action(ODOM, ODATA)
         sf.update_sensor(data)
         w_after = b.samples.copy()
         sf.update_resample()
@@ -70,6 +75,7 @@ def test_two_shards_equal_one_filter(tmp_path, split):
     opf.set_samples(sc.samples)
     p = sc.oracle_planar(61, "lf")
     for cycle in range(2):
+        opf.pf.rng = orc.odom_update_action(ODOM[0], ODOM[1], *ODATA, opf.samples[:opf.sample_count], opf.pf.rng)
         opf.update_sensor(lambda s, conv: sc.oracle_apply(p, s, conv))
         w_ref = opf.samples[:opf.sample_count, 3].copy()
         out = opf.update_resample()
