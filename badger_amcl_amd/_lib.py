@@ -75,6 +75,7 @@ SIGNATURES = {
     "bpf_map2d_build_distances_lut_reference": (C.c_int, [_vp, C.c_double]),
     "bpf_wire_laserscan_to_planar": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_double,
                                                C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]),
+    "bpf_wire_scan_angle_stats": (C.c_int, [C.c_double, C.c_double, _dp, _dp, _dp]),
     "bpf_wire_occupancy_grid_to_cells": (C.c_int, [C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_double, C.c_double,
                                                    C.c_double, C.c_int, C.POINTER(C.c_int32), _ip, _ip,
                                                    C.POINTER(C.c_float), _dp]),
@@ -82,6 +83,9 @@ SIGNATURES = {
     "bpf_wire_samples_to_pose_array": (C.c_int, [_dp, C.c_int, _dp]),
     "bpf_map3d_set": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, _ip, _ip,
                                 C.c_double, C.c_double]),
+    "bpf_map3d_build_distances_lut": (C.c_int, [_vp, _ip, C.c_size_t, _ip, _ip, C.c_double, C.c_double]),
+    "bpf_map3d_get_distances_lut": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
     "bpf_cloud_init": (C.c_int, [_vp, C.c_int]),
     "bpf_cloud_set_model": (C.c_int, [_vp] + [C.c_double] * 3),
     "bpf_cloud_set_model_gompertz": (C.c_int, [_vp] + [C.c_double] * 9),

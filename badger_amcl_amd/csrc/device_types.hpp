@@ -14,7 +14,8 @@ namespace bpf
 //    border of one cell on every side filled with the off-map level K: an end point is
 //    clamped into [0, size+1] per axis (one unsigned min) and looked up without a bounds test.
 //    The stored value is level*8, the byte offset of the level's term in the per-scan table.
-//    Byte offset of padded cell (u, v):  (v&~7)*(16*ltx-16) + 16*v + (u&~7)*14 + 2*u.
+//    Inside a tile the cells are stored u-major ((u&7)*8 + (v&7)), which makes the byte offset of padded
+//    cell (u, v) a sum with a single masked term:  16*u + 2*v + (16*ltx - 2)*(v & ~7).
 //  * cheb: for raycasts, one byte per cell of the map padded by one cell all round (row-major,
 //    padded cell (x+1, y+1), row length size_x+2): chessboard distance to the nearest cell that is
 //    not CELL_FREE or lies outside the map (the ring counts as blocked), capped at 255.

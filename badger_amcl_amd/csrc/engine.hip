@@ -184,6 +184,7 @@ struct bpf_engine
   double map3_max_dist = 0.0;
   DevBuf<uint32_t> d_pose_indices;
   DevBuf<uint8_t> d_ratios;
+  size_t n_pose_indices = 0, n_ratios = 0;
   bool cloud_configured = false;
   int cloud_max_beams = 0;
   double cloud_z_hit = 0, cloud_z_rand = 0, cloud_sigma = 0;
@@ -386,7 +387,7 @@ int encode_lut(bpf_engine* e, const float* lut)
         prev_bits = bits;
       }
       const int u = i + 1, v = j + 1;
-      tiles[((size_t)(v >> 3) * tx + (u >> 3)) * 64 + ((v & 7) << 3) + (u & 7)] = (uint16_t)(prev_idx * 8);
+      tiles[((size_t)(v >> 3) * tx + (u >> 3)) * 64 + ((u & 7) << 3) + (v & 7)] = (uint16_t)(prev_idx * 8);
     }
   }
   HIPCHK(e, e->d_lut_tiles.reserve(tiles.size()));
@@ -618,7 +619,8 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   const bool count_only = obs_count != nullptr;
   const bool table_lds = !count_only && fs.table_len <= kTableLdsMax;
   const size_t table_bytes = table_lds ? (((size_t)fs.table_len * sizeof(double) + 15) & ~(size_t)15) : 0;
-  const size_t lds = (size_t)fs.n_staged * sizeof(double2) + table_bytes;
+  // at least the four block partials that reuse the head of the block (kernels_score.hpp)
+  const size_t lds = std::max<size_t>(32, (size_t)fs.n_staged * sizeof(double2) + table_bytes);
   // per-particle scanner pose / trig once per update (shared by both scoring forms)
   const int prep_blocks = blocks_for(n, 256);
   HIPCHK(e, e->d_prep.reserve((size_t)n));
@@ -2318,6 +2320,55 @@ int bpf_wire_laserscan_to_planar(const float* ranges, int n, float msg_range_min
   return BPF_OK;
 }
 
+namespace
+{
+struct Quat
+{
+  double x, y, z, w;
+};
+Quat quat_from_yaw(double yaw)
+{
+  // tf2::Quaternion::setRPY(0, 0, yaw): with zero roll / pitch the products reduce to this
+  const double h = yaw * 0.5;
+  return Quat{ 0.0, 0.0, std::sin(h), std::cos(h) };
+}
+Quat quat_mul(const Quat& a, const Quat& b)
+{
+  // tf2 operator*(Quaternion, Quaternion)
+  return Quat{ a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+               a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z };
+}
+double quat_yaw(const Quat& q)
+{
+  // tf2::getYaw (tf2/impl/utils.h): gimbal-lock cases first, then the usual atan2
+  const double sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
+  const double sarg = -2 * (q.x * q.z - q.w * q.y) / (sqx + sqy + sqz + sqw);
+  if (sarg <= -0.99999)
+    return -2 * std::atan2(q.y, q.x);
+  if (sarg >= 0.99999)
+    return 2 * std::atan2(q.y, q.x);
+  return std::atan2(2 * (q.x * q.y + q.w * q.z), sqw + sqx - sqy - sqz);
+}
+}  // namespace
+
+int bpf_wire_scan_angle_stats(double msg_angle_min, double msg_angle_increment, const double q_base_from_scanner[4],
+                              double* angle_min_out, double* angle_increment_out)
+{
+  if (!q_base_from_scanner || !angle_min_out || !angle_increment_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  const Quat t{ q_base_from_scanner[0], q_base_from_scanner[1], q_base_from_scanner[2], q_base_from_scanner[3] };
+  // node_2d.cpp:503-526: doTransform on a quaternion message is t.rotation * q
+  const Quat min_q = quat_mul(t, quat_from_yaw(msg_angle_min));
+  const Quat inc_q = quat_mul(t, quat_from_yaw(msg_angle_min + msg_angle_increment));
+  const double amin = quat_yaw(min_q);
+  double inc = quat_yaw(inc_q) - amin;
+  const double r = std::fmod(inc + M_PI, 2.0 * M_PI);  // angles::normalize_angle, Noetic form
+  inc = (r <= 0.0) ? r + M_PI : r - M_PI;
+  *angle_min_out = amin;
+  *angle_increment_out = inc;
+  return BPF_OK;
+}
+
 int bpf_wire_occupancy_grid_to_cells(const int8_t* data, int width, int height, double msg_resolution,
                                      double msg_origin_x, double msg_origin_y, int map_scale_up_factor,
                                      int32_t* cells_out, int* size_x_out, int* size_y_out, float origin_out[2],
@@ -2423,7 +2474,143 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
   M.resolution = resolution;
   M.inv_resolution = 1.0 / resolution;
   e->map3_max_dist = max_dist;
+  e->n_pose_indices = n_pose_indices;
+  e->n_ratios = n_distance_ratios;
   e->have_map3d = true;
+  return BPF_OK;
+}
+
+int bpf_map3d_build_distances_lut(bpf_engine* e, const int* occupied_ijk, size_t n_occupied, const int min_cells[3],
+                                  const int max_cells[3], double resolution, double max_dist)
+{
+  if (!e || (!occupied_ijk && n_occupied) || !min_cells || !max_cells || !(resolution > 0))
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad 3-D map arguments") : BPF_ERR_INVALID_ARGUMENT;
+  if (max_dist == 0.0)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "max distance to object is 0 (octomap.cpp:177-181)");
+  const long long w = (long long)max_cells[0] - min_cells[0] + 1, h = (long long)max_cells[1] - min_cells[1] + 1,
+                  nz = (long long)max_cells[2] - min_cells[2] + 1;
+  if (w <= 0 || h <= 0 || nz <= 0 || w * h > 0x7fffffffll)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "bad cell bounds");
+  struct Cell
+  {
+    int i, j, k, si, sj, sk;
+  };
+  struct Index3
+  {
+    int v[3];
+    bool operator<(const Index3& o) const  // octomap.h:51-54
+    {
+      return v[0] != o.v[0] ? v[0] < o.v[0] : v[1] != o.v[1] ? v[1] < o.v[1] : v[2] < o.v[2];
+    }
+  };
+  std::vector<uint32_t> pose_indices((size_t)(w * h), 0u);
+  std::vector<uint8_t> ratios((size_t)nz, 255);  // the shared all-255 column 0 (octomap.cpp:189-190)
+  const double ratio_unit = max_dist / 255;      // max_distance_ratio_ (octomap.cpp:57)
+  auto column = [&](int i, int j) { return (size_t)(j - min_cells[1]) * (size_t)w + (size_t)(i - min_cells[0]); };
+  auto get = [&](int i, int j, int k) {  // getDistanceToObject :336-350
+    return ratios[(size_t)pose_indices[column(i, j)] + (size_t)(k - min_cells[2])] * ratio_unit;
+  };
+  bool too_big = false;
+  auto set = [&](int i, int j, int k, double d) {  // setDistanceToObject :314-333
+    uint32_t& start = pose_indices[column(i, j)];
+    if (start == 0)
+    {
+      if (ratios.size() + (size_t)nz > 0xffffffffull)
+      {
+        too_big = true;
+        return;
+      }
+      start = (uint32_t)ratios.size();
+      ratios.resize(ratios.size() + (size_t)nz, 255);
+    }
+    d = std::min(d, max_dist);
+    d = d / max_dist * 255;
+    ratios[(size_t)start + (size_t)(k - min_cells[2])] = (uint8_t)static_cast<int>(std::floor(d));
+  };
+  // CachedDistanceOctoMap (:152-172)
+  const int radius = static_cast<int>(std::floor(max_dist / resolution));
+  const int td = radius + 2;
+  std::vector<double> cached((size_t)td * td * td);
+  for (int a = 0; a < td; ++a)
+    for (int b = 0; b < td; ++b)
+      for (int c = 0; c < td; ++c)
+        cached[((size_t)a * td + b) * td + c] = std::sqrt((double)(a * a + b * b + c * c)) * resolution;
+  // iterateObstacleCells (:208-249): zero distance in iteration order, FIFO seeded in descending Index3 order
+  std::priority_queue<Index3> ordering;
+  for (size_t q = 0; q < n_occupied; ++q)
+  {
+    const int* v = &occupied_ijk[3 * q];
+    bool valid = true;
+    for (int d = 0; d < 3; ++d)
+      valid = valid && v[d] >= min_cells[d] && v[d] <= max_cells[d];
+    if (!valid)
+      continue;
+    set(v[0], v[1], v[2], 0.0);
+    ordering.push(Index3{ { v[0], v[1], v[2] } });
+  }
+  std::queue<Cell> fifo;
+  while (!ordering.empty())
+  {
+    const Index3 s = ordering.top();
+    ordering.pop();
+    fifo.push(Cell{ s.v[0], s.v[1], s.v[2], s.v[0], s.v[1], s.v[2] });
+  }
+  // iterateEmptyCells / enqueue (:251-311)
+  static const int kShifts[6][3] = { { -1, 0, 0 }, { 0, -1, 0 }, { 0, 0, -1 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+  while (!fifo.empty() && !too_big)
+  {
+    const Cell cur = fifo.front();
+    const bool open[6] = { cur.i > min_cells[0], cur.j > min_cells[1], cur.k > min_cells[2],
+                           cur.i < max_cells[0], cur.j < max_cells[1], cur.k < max_cells[2] };
+    for (int s = 0; s < 6; ++s)
+    {
+      if (!open[s])
+        continue;
+      const int i = cur.i + kShifts[s][0], j = cur.j + kShifts[s][1], k = cur.k + kShifts[s][2];
+      const int di = std::abs(i - cur.si), dj = std::abs(j - cur.sj), dk = std::abs(k - cur.sk);
+      if (di >= td || dj >= td || dk >= td)
+        continue;  // the reference indexes its table unchecked; a cell this far out was never improved on the way
+      const double new_distance = cached[((size_t)di * td + dj) * td + dk];
+      const double old_distance = get(i, j, k);
+      if (old_distance - new_distance > ratio_unit)
+      {
+        set(i, j, k, new_distance);
+        fifo.push(Cell{ i, j, k, cur.si, cur.sj, cur.sk });
+      }
+    }
+    fifo.pop();
+  }
+  if (too_big)
+    return e->fail(BPF_ERR_CAPACITY, "distance_ratios would pass the 32-bit column index range");
+  return bpf_map3d_set(e, pose_indices.data(), pose_indices.size(), ratios.data(), ratios.size(), min_cells, max_cells,
+                       resolution, max_dist);
+}
+
+int bpf_map3d_get_distances_lut(bpf_engine* e, uint32_t* pose_indices, size_t pose_capacity, size_t* n_pose_indices,
+                                uint8_t* distance_ratios, size_t ratios_capacity, size_t* n_distance_ratios)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_map3d)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 3-D map set");
+  if (n_pose_indices)
+    *n_pose_indices = e->n_pose_indices;
+  if (n_distance_ratios)
+    *n_distance_ratios = e->n_ratios;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (pose_indices)
+  {
+    if (pose_capacity < e->n_pose_indices)
+      return e->fail(BPF_ERR_CAPACITY, "pose_indices output too small");
+    HIPCHK(e, hipMemcpy(pose_indices, e->d_pose_indices.p, e->n_pose_indices * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  if (distance_ratios)
+  {
+    if (ratios_capacity < e->n_ratios)
+      return e->fail(BPF_ERR_CAPACITY, "distance_ratios output too small");
+    HIPCHK(e, hipMemcpy(distance_ratios, e->d_ratios.p, e->n_ratios, hipMemcpyDeviceToHost));
+  }
   return BPF_OK;
 }
 

@@ -54,13 +54,18 @@ __device__ __forceinline__ unsigned clamp_cell(int c, int size)
   return min((unsigned)c, (unsigned)(size + kLutPad));
 }
 
-// byte offset of padded cell (u, v) in lut_tiles (see MapDev)
+// byte offset of padded cell (u, v) in lut_tiles (see MapDev): tile (v>>3, u>>3), cell (u&7)*8 + (v&7) inside it,
+//   128*((v>>3)*ltx + (u>>3)) + 16*(u&7) + 2*(v&7)  =  16*u + 2*v + (16*ltx - 2)*(v & ~7)
+// -- four VALU operations (shift, shift-add, and, 24-bit multiply-add), one masked term only.
 __device__ __forceinline__ unsigned lut_byte_offset(const MapDev& m, unsigned u, unsigned v)
 {
-  const unsigned a = u & ~7u, b = v & ~7u;
-  const unsigned t = __umul24(a, 14u) + (u << 1);
-  const unsigned t2 = __umul24(b, (unsigned)(16 * m.ltx - 16)) + t;
-  return (v << 4) + t2;
+  const unsigned t = (u << 4) + (v << 1);
+  const unsigned vh = v & ~7u, k = (unsigned)(16 * m.ltx - 2);
+  // the compiler splits `vh * k + t` into v_mul_u32_u24 + v_add3_u32 with the two shifts (5 operations);
+  // stating the multiply-add keeps it at shift, shift-add, and, multiply-add
+  unsigned off;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(vh), "s"(k), "v"(t));
+  return off;
 }
 
 // the stored 16-bit value is (level index * 8) = byte offset of the level's term in the term table
@@ -343,9 +348,13 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
   }
   if (!COUNT_ONLY && A.block_partials != nullptr)
   {
-    // fixed shape: lanes -> wave (xor tree), waves 0..3 in order: reproducible for a given grid
-    __shared__ double s_part[4];
+    // fixed shape: lanes -> wave (xor tree), waves 0..3 in order: reproducible for a given grid.
+    // The four partials reuse the head of the dynamic LDS block once every wave is done with the
+    // tables: a static __shared__ array would push the term table off LDS address 0 and cost one
+    // address add per table read in the inner loop.
     const double ws = wave_sum(wsum);
+    __syncthreads();
+    double* s_part = reinterpret_cast<double*>(smem);
     if (lane == 0)
       s_part[wave] = ws;
     __syncthreads();

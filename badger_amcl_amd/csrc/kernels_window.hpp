@@ -239,16 +239,14 @@ __global__ __launch_bounds__(kWinThreads) void k_score_window(const WindowScoreA
   const int tid = threadIdx.x;
   const int stride = D.wu;  // cells per LDS row (multiple of 8)
 
-  // stage the window: 16-byte tile-row segments (8 cells) straight from the tiled image (entries are
-  // already level*8, the byte offset of the level's term)
-  const int segs_per_row = D.wu >> 3;
-  const int n_segs = segs_per_row * D.wv;
-  for (int sidx = tid; sidx < n_segs; sidx += kWinThreads)
+  // stage the window cell by cell from the tiled image (entries are already level*8, the byte offset of the
+  // level's term); consecutive threads walk v first, i.e. along a tile's 16-byte columns
+  const int n_cells = D.wu * D.wv;
+  for (int c = tid; c < n_cells; c += kWinThreads)
   {
-    const int dv = sidx / segs_per_row, du = (sidx - dv * segs_per_row) << 3;
-    const uint4 seg = *reinterpret_cast<const uint4*>(tiles + lut_byte_offset(M, (unsigned)(D.u0 + du),
-                                                                                (unsigned)(D.v0 + dv)));
-    *reinterpret_cast<uint4*>(&s_win[dv * stride + du]) = seg;
+    const int du = c / D.wv, dv = c - du * D.wv;
+    s_win[dv * stride + du] = *reinterpret_cast<const uint16_t*>(
+        tiles + lut_byte_offset(M, (unsigned)(D.u0 + du), (unsigned)(D.v0 + dv)));
   }
   for (int i = tid; i < A.table_len; i += kWinThreads)
     s_table[i] = A.table[i];

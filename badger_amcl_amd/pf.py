@@ -416,6 +416,27 @@ class OctoMap:
                                               mx.ctypes.data_as(C.POINTER(C.c_int)), self.resolution,
                                               self.max_distance_to_object))
 
+    def updateDistancesLUT(self, occupied_ijk, min_cells, max_cells, max_distance_to_object):
+        """OctoMap::updateDistancesLUT (octomap.cpp:175-333) from the occupied voxel indices (octree leaf order)."""
+        occ = np.ascontiguousarray(occupied_ijk, dtype=np.int32).reshape(-1, 3)
+        mn = np.ascontiguousarray(min_cells, dtype=np.int32)
+        mx = np.ascontiguousarray(max_cells, dtype=np.int32)
+        self.max_distance_to_object = float(max_distance_to_object)
+        self.e.check(self.e.lib.bpf_map3d_build_distances_lut(
+            self.e.h, occ.ctypes.data_as(C.POINTER(C.c_int)), occ.shape[0], mn.ctypes.data_as(C.POINTER(C.c_int)),
+            mx.ctypes.data_as(C.POINTER(C.c_int)), self.resolution, self.max_distance_to_object))
+
+    def getDistancesLUT(self):
+        """(pose_indices uint32, distance_ratios uint8) as held on the device."""
+        npi, ndr = C.c_size_t(), C.c_size_t()
+        self.e.check(self.e.lib.bpf_map3d_get_distances_lut(self.e.h, None, 0, C.byref(npi), None, 0, C.byref(ndr)))
+        pi = np.zeros(npi.value, dtype=np.uint32)
+        dr = np.zeros(ndr.value, dtype=np.uint8)
+        self.e.check(self.e.lib.bpf_map3d_get_distances_lut(
+            self.e.h, pi.ctypes.data_as(C.POINTER(C.c_uint32)), pi.size, None,
+            dr.ctypes.data_as(C.POINTER(C.c_uint8)), dr.size, None))
+        return pi, dr
+
 
 class PointCloudData:
     """include/amcl/sensors/point_cloud_scanner.h:45-51 (points_ as packed float xyz)"""

@@ -29,6 +29,15 @@ def laserscan_to_planar(ranges_f32, msg_range_min, msg_range_max, angle_min, ang
     return ro, ao, rm.value
 
 
+def scan_angle_stats(msg_angle_min, msg_angle_increment, q_base_from_scanner_xyzw):
+    """Node2D::getAngleStats (node_2d.cpp:497-529) -> (angle_min, angle_increment) in the base frame."""
+    q = np.ascontiguousarray(q_base_from_scanner_xyzw, dtype=np.float64)
+    a, b = C.c_double(), C.c_double()
+    _check(_lib.load().bpf_wire_scan_angle_stats(msg_angle_min, msg_angle_increment,
+                                                 q.ctypes.data_as(C.POINTER(C.c_double)), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def occupancy_grid_to_cells(data_i8, width, height, resolution, origin_x, origin_y, map_scale_up_factor=1):
     """Node2D::convertMap (node_2d.cpp:265-295) -> (cells int32 [size_y, size_x], origin f32[2], resolution)."""
     d = np.ascontiguousarray(data_i8, dtype=np.int8).reshape(-1)

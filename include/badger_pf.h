@@ -238,6 +238,18 @@ int bpf_pf_get_max_weight_pose(bpf_engine* e, double* max_weight, double pose[3]
 int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_indices,
                   const uint8_t* distance_ratios, size_t n_distance_ratios, const int min_cells[3],
                   const int max_cells[3], double resolution, double max_dist);
+
+/* OctoMap::updateDistancesLUT (octomap.cpp:175-333) from the occupied voxel indices instead of an octree
+ * (the octomap library is the caller's): `occupied_ijk` = n x (i, j, k) map cells of the occupied leaves in
+ * the octree's leaf-iteration order (that order fixes where each z column lands in distance_ratios);
+ * min_cells / max_cells = cropped_min_cells_ / cropped_max_cells_.  FIFO brushfire with the reference's uint8
+ * quantisation and seeding order (priority_queue<Index3>, octomap.h:49-55), run on the host; the result is
+ * uploaded like bpf_map3d_set.  SURVEY 8(f) next-3. */
+int bpf_map3d_build_distances_lut(bpf_engine* e, const int* occupied_ijk, size_t n_occupied, const int min_cells[3],
+                                  const int max_cells[3], double resolution, double max_dist);
+/* copies out what the builder (or bpf_map3d_set) holds; either pointer may be NULL to query the sizes only */
+int bpf_map3d_get_distances_lut(bpf_engine* e, uint32_t* pose_indices, size_t pose_capacity, size_t* n_pose_indices,
+                                uint8_t* distance_ratios, size_t ratios_capacity, size_t* n_distance_ratios);
 /* PointCloudScanner::{init, setPointCloudModel, setPointCloudModelGompertz, setMapFactors,
  * setPointCloudScannerToFootprintTF} (point_cloud_scanner.cpp:48-90). */
 int bpf_cloud_init(bpf_engine* e, int max_beams);
@@ -317,6 +329,12 @@ int bpf_wire_laserscan_to_planar(const float* ranges, int n, float msg_range_min
                                  double sensor_min_range, double sensor_max_range, double angle_min,
                                  double angle_increment, double* ranges_out, double* angles_out,
                                  double* range_max_out);
+/* Node2D::getAngleStats (node_2d.cpp:497-529): first bearing and bearing increment of a scanner in the base
+ * frame (an upside-down scanner gets a negative increment).  q_base_from_scanner = rotation (x, y, z, w)
+ * of the base_frame <- scan frame transform the node looks up.  Quaternion helpers are third-party tf2
+ * (setRPY, operator*, getYaw), restated from their published form. */
+int bpf_wire_scan_angle_stats(double msg_angle_min, double msg_angle_increment, const double q_base_from_scanner[4],
+                              double* angle_min_out, double* angle_increment_out);
 /* Node2D::convertMap (node_2d.cpp:265-295): nav_msgs/OccupancyGrid -> tri-state cells with integer
  * up-scaling and the centre origin (narrowed to float like pcl::PointXYZ).  cells_out holds
  * (width*scale) * (height*scale) int32. */

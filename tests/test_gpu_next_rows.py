@@ -98,3 +98,23 @@ def test_reference_brushfire_lut_is_bit_identical(engine, orc):
         m.updateDistancesLUTReference(max_dist)
         got = m.getDistancesLUT()
         assert np.array_equal(got.reshape(-1), np.asarray(want, dtype=np.float32).reshape(-1))
+
+
+def test_octomap_lut_builder_matches_oracle(engine, orc):
+    """bpf_map3d_build_distances_lut == OctoMap::updateDistancesLUT (oracle restatement): same column
+    placement (octree leaf order = list order) and the same quantised distances, byte for byte."""
+    import badger_amcl_amd as bpf
+    occ = synth.box_room_voxels(lo=(-12, -9, -2), hi=(12, 9, 6))
+    rng = np.random.default_rng(4)
+    occ = occ[rng.permutation(occ.shape[0])]          # an arbitrary "leaf iteration" order
+    extra = np.array([[100, 0, 0], [0, -50, 1]], dtype=np.int32)  # outside the cropped bounds: skipped
+    occ = np.ascontiguousarray(np.concatenate([occ[:50], extra, occ[50:]]))
+    mn, mx = (-14, -11, -3), (14, 11, 8)
+    for res, max_dist in [(0.05, 0.3), (0.1, 0.45)]:
+        want = orc.OctoMapLUT(mn, mx, res, max_dist)
+        want.build(occ)
+        om = bpf.OctoMap(engine, res)
+        om.updateDistancesLUT(occ, mn, mx, max_dist)
+        pi, dr = om.getDistancesLUT()
+        assert np.array_equal(pi, want.pose_indices)
+        assert np.array_equal(dr, want.distance_ratios)

@@ -28,6 +28,21 @@ def test_laserscan_to_planar_matches_node2d():
         assert np.array_equal(ao, amin + np.arange(1081) * ainc)
 
 
+def test_scan_angle_stats_upright_and_upside_down():
+    """node_2d.cpp:497-529: an upright scanner yawed by 0.3 shifts angle_min; one rolled by pi
+    (mounted upside-down) mirrors the sweep: angle_min -> -angle_min, increment -> -increment."""
+    amin, ainc = -2.0, 0.005
+    a, b = wire.scan_angle_stats(amin, ainc, (0.0, 0.0, 0.0, 1.0))
+    assert abs(a - amin) < 1e-15 and abs(b - ainc) < 1e-15
+    a, b = wire.scan_angle_stats(amin, ainc, (0.0, 0.0, math.sin(0.15), math.cos(0.15)))
+    assert abs(a - (amin + 0.3)) < 1e-15 and abs(b - ainc) < 1e-15
+    a, b = wire.scan_angle_stats(amin, ainc, (1.0, 0.0, 0.0, 0.0))  # roll = pi
+    assert abs(a + amin) < 1e-15 and abs(b + ainc) < 1e-15
+    # wrap of the increment into [-pi, pi): first bearing near +pi
+    a, b = wire.scan_angle_stats(math.pi - 0.001, 0.004, (0.0, 0.0, 0.0, 1.0))
+    assert abs(b - 0.004) < 1e-12
+
+
 def test_laserscan_empty():
     ro, ao, rmax = wire.laserscan_to_planar(np.zeros(0, np.float32), 0.1, 30.0, 0.0, 0.01)
     assert ro.size == 0 and ao.size == 0 and rmax == float(np.float32(30.0))
