@@ -1023,6 +1023,21 @@ int launch_converged(bpf_engine* e)
   return BPF_OK;
 }
 
+// Spin on the generation word a kernel publishes in pinned host memory (kernels of ~10 us); false if it
+// takes implausibly long, and the caller falls back to a copy + stream synchronisation.
+bool wait_generation(bpf_engine* e, unsigned generation)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins)
+  {
+    if (__atomic_load_n(e->h_done.p, __ATOMIC_ACQUIRE) == generation)
+      return true;
+    if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+      return false;
+    __builtin_ia32_pause();
+  }
+}
+
 int resample_multinomial(bpf_engine* e)
 {
   SampleSet& a = e->sets[e->cur];
@@ -1071,24 +1086,7 @@ int resample_multinomial(bpf_engine* e)
       hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(wn, 256)), dim3(256), 0, e->stream, A);
     }
     HIPCHK(e, hipGetLastError());
-    bool have_keys = false;
-    if (zero_copy)
-    {
-      // bounded spin (a kernel of ~10 us): fall back to a plain synchronise if it takes implausibly long
-      const auto t0 = std::chrono::steady_clock::now();
-      for (unsigned spins = 0;; ++spins)
-      {
-        if (__atomic_load_n(e->h_done.p, __ATOMIC_ACQUIRE) == A.generation)
-        {
-          have_keys = true;
-          break;
-        }
-        if ((spins & 1023) == 1023 &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
-          break;
-        __builtin_ia32_pause();
-      }
-    }
+    const bool have_keys = zero_copy && wait_generation(e, A.generation);
     int k_stride = wn;
     if (!have_keys)
     {
@@ -1169,20 +1167,46 @@ int resample_systematic(bpf_engine* e)
         t -= 1.0;
     }
   }
-  HIPCHK(e, hipMemcpyAsync(e->d_targets.p, e->h_targets.p, (size_t)count * sizeof(double), hipMemcpyHostToDevice,
-                           e->stream));
+  // the kernel reads the targets straight from the pinned buffer (28 KB for 3.5 k samples) and, like the
+  // multinomial draw kernel, leaves the keys in pinned memory behind a generation word
+  A.targets = e->h_targets.p;
+  const bool zero_copy = e->zero_copy_keys && count <= (1 << 20);
+  if (zero_copy)
+  {
+    A.host_keys = e->h_keys.p;
+    A.host_stride = count;
+    A.done_counter = reinterpret_cast<unsigned*>(e->d_flags.p + 4);
+    A.host_done = reinterpret_cast<volatile unsigned*>(e->h_done.p);
+    A.generation = ++e->done_generation;
+  }
   {
     ProfScope ps(e, BPF_K_DRAW);
     hipLaunchKernelGGL(k_systematic_select, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream, A);
   }
   HIPCHK(e, hipGetLastError());
-  HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)count * 3 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  int k_stride = count;
+  if (!(zero_copy && wait_generation(e, A.generation)))
+  {
+    if (zero_copy)  // the kernel wrote the host rows; wait for it the slow way
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+    else
+    {
+      HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)count * 3 * sizeof(int), hipMemcpyDeviceToHost,
+                               e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      k_stride = 0;
+    }
+  }
   e->hist.clear();
   e->seen.reset((size_t)std::min(count, 1 << 20));
+  const int* keys = e->h_keys.p;
   for (int m = 0; m < count; ++m)
-    if (e->seen.first_time(e->h_keys.p[3 * m], e->h_keys.p[3 * m + 1], e->h_keys.p[3 * m + 2]))
-      e->hist.insert(e->h_keys.p[3 * m], e->h_keys.p[3 * m + 1], e->h_keys.p[3 * m + 2]);
+  {
+    const int k0 = k_stride ? keys[m] : keys[3 * m], k1 = k_stride ? keys[k_stride + m] : keys[3 * m + 1],
+              k2 = k_stride ? keys[2 * k_stride + m] : keys[3 * m + 2];
+    if (e->seen.first_time(k0, k1, k2))
+      e->hist.insert(k0, k1, k2);
+  }
   e->resample_windows = 1;
   e->sample_count = count;
   return BPF_OK;

@@ -778,6 +778,12 @@ struct SystematicArgs
   int* keys;
   int* src_index;
   int* miss_flag;
+  // zero-copy hand-off (as DrawArgs): keys as three rows in pinned host memory + generation word
+  int* host_keys;
+  int host_stride;
+  unsigned* done_counter;
+  volatile unsigned* host_done;
+  unsigned generation;
 };
 
 // The reference walks the CDF cyclically from the previous hit (particle_filter.cpp:329-336);
@@ -785,20 +791,36 @@ struct SystematicArgs
 __global__ void k_systematic_select(const SystematicArgs A)
 {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= A.count)
-    return;
-  int i = cdf_find(A.cdf, A.n_src, A.targets[m]);
-  if (i >= A.n_src)
+  if (m < A.count)
   {
-    atomicExch(A.miss_flag, 1);  // the reference never leaves its while loop here
-    i = A.n_src - 1;
+    int i = cdf_find(A.cdf, A.n_src, A.targets[m]);
+    if (i >= A.n_src)
+    {
+      atomicExch(A.miss_flag, 1);  // the reference never leaves its while loop here
+      i = A.n_src - 1;
+    }
+    const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
+    A.dst.x[m] = x;
+    A.dst.y[m] = y;
+    A.dst.th[m] = th;
+    A.src_index[m] = i;
+    int key[3];
+    pose_key(x, y, th, key);
+    if (A.host_keys != nullptr)
+    {
+      A.host_keys[m] = key[0];
+      A.host_keys[A.host_stride + m] = key[1];
+      A.host_keys[2 * A.host_stride + m] = key[2];
+    }
+    else
+    {
+      A.keys[3 * m] = key[0];
+      A.keys[3 * m + 1] = key[1];
+      A.keys[3 * m + 2] = key[2];
+    }
   }
-  const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
-  A.dst.x[m] = x;
-  A.dst.y[m] = y;
-  A.dst.th[m] = th;
-  A.src_index[m] = i;
-  pose_key(x, y, th, &A.keys[3 * m]);
+  if (A.host_keys != nullptr)
+    publish_when_last(A.done_counter, A.host_done, A.generation);
 }
 
 __global__ void k_pose_keys(ParticlesDev p, int n, int* __restrict__ keys)
