@@ -3081,6 +3081,26 @@ int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride
   return BPF_OK;
 }
 
+int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int first_draw_index,
+                     int* stop_count_out)
+{
+  if (!e || !window_dev || !stop_count_out || stride < n_keys || n_keys <= 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, e->h_keys.reserve((size_t)n_keys * 3));
+  const unsigned generation = ++e->done_generation;
+  hipLaunchKernelGGL(k_publish_window_keys, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
+                     static_cast<const long long*>(window_dev), stride, n_keys, e->h_keys.p,
+                     reinterpret_cast<unsigned*>(e->d_flags.p + 4), reinterpret_cast<volatile unsigned*>(e->h_done.p),
+                     generation);
+  HIPCHK(e, hipGetLastError());
+  if (!wait_generation(e, generation))
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  return bpf_kld_feed(e, e->h_keys.p, 0, n_keys, n_keys, first_draw_index, stop_count_out);
+}
+
 int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out)
 {
   if (!e)

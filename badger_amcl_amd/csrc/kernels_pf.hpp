@@ -823,6 +823,20 @@ __global__ void k_systematic_select(const SystematicArgs A)
     publish_when_last(A.done_counter, A.host_done, A.generation);
 }
 
+// rows 3..5 of an int64 draw window -> three int rows in pinned host memory, then the generation word
+__global__ void k_publish_window_keys(const long long* __restrict__ window, int stride, int n, int* host_keys,
+                                      unsigned* done_counter, volatile unsigned* host_done, unsigned generation)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n)
+  {
+    host_keys[q] = (int)window[(size_t)3 * stride + q];
+    host_keys[n + q] = (int)window[(size_t)4 * stride + q];
+    host_keys[2 * n + q] = (int)window[(size_t)5 * stride + q];
+  }
+  publish_when_last(done_counter, host_done, generation);
+}
+
 __global__ void k_pose_keys(ParticlesDev p, int n, int* __restrict__ keys)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

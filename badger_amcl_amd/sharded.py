@@ -90,6 +90,13 @@ class HipShardBackend:
                                              C.byref(stop)))
         return stop.value
 
+    def kld_feed_window(self, window, n, first):
+        """Keys = rows 3..5 of the assembled device window; no torch copy, no stream synchronisation."""
+        stop = C.c_int(-1)
+        self.e.check(self.e.lib.bpf_kld_feed_dev(self.e.h, C.c_void_p(window.data_ptr()), window.shape[1], n, first,
+                                                 C.byref(stop)))
+        return stop.value
+
     def kld_counts(self):
         a, b = C.c_int(), C.c_int()
         self.e.check(self.e.lib.bpf_kld_leaf_count(self.e.h, C.byref(a), C.byref(b)))
@@ -205,8 +212,7 @@ class ShardedFilter:
                 self._windows[(cnt, len(windows))] = window
             b.draw_window(rng, m0, m1, sums, sums_are_totals, self.rank, W, window, self.flags)
             self._all_reduce_sum(window)
-            keys = window[3:6].cpu().contiguous()  # the one host sync of the window
-            stop = b.kld_feed(keys, cnt, m0)
+            stop = b.kld_feed_window(window, cnt, m0)  # the one host wait of the window
             windows.append((m0, cnt, window))
             self.windows_used += 1
             m0 = m1

@@ -319,6 +319,11 @@ uint64_t bpf_drand48_skip(uint64_t state48, uint64_t n);
 int bpf_kld_reset(bpf_engine* e);
 int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys, int first_draw_index,
                  int* stop_count_out);
+/* the same with the keys still on the device: rows 3..5 of an assembled draw window (int64 [6][stride], see
+ * bpf_shard_draw_window_dev).  A copy kernel on the engine's stream leaves them in pinned host memory behind a
+ * generation word the host spins on (no D2H copy call, no stream synchronisation), then the replay runs. */
+int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int first_draw_index,
+                     int* stop_count_out);
 int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out);
 
 /* ------------------------------------------------------------------ wire formats

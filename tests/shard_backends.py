@@ -132,6 +132,9 @@ class OracleShardBackend:
                 return count
         return -1
 
+    def kld_feed_window(self, window, n, first):
+        return self.kld_feed(window[3:6].contiguous(), n, first)
+
     def kld_counts(self):
         return self.tree.leaf_count(), self.tree.node_count()
 
