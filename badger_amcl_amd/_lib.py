@@ -13,7 +13,8 @@ class PFState(C.Structure):
     _fields_ = [("sample_count", C.c_int), ("leaf_count", C.c_int), ("bin_count", C.c_int),
                 ("converged", C.c_int), ("percent_converged", C.c_float),
                 ("total", C.c_double), ("w_slow", C.c_double), ("w_fast", C.c_double), ("w_diff", C.c_double),
-                ("last_status", C.c_int), ("resample_windows", C.c_int), ("evals", C.c_longlong)]
+                ("last_status", C.c_int), ("resample_windows", C.c_int), ("evals", C.c_longlong),
+                ("kld_on_device", C.c_int), ("reserved", C.c_int)]
 
 
 class Cluster(C.Structure):

@@ -18,6 +18,7 @@
 #include "kdhist.hpp"
 #include "kernels_cloud.hpp"
 #include "kernels_motion.hpp"
+#include "kernels_kld.hpp"
 #include "kernels_pf.hpp"
 #include "kernels_score.hpp"
 #include "kernels_window.hpp"
@@ -236,6 +237,17 @@ struct bpf_engine
   SampleSet scratch;  // Seam A host-buffer path
   SampleSet snap;
   int snap_count = 0, snap_leaf = 0, snap_bins = 0;
+
+  // ---- KLD stop rule on the device (long draw streams)
+  int kld_device_min = 8192;  // draws left after the first window from which the device tree takes over
+  bool kld_device_used = false;
+  int kld_leaf = 0, kld_bins = 0;
+  DevBuf<unsigned long long> d_kld_hkey;
+  DevBuf<int> d_kld_htmin, d_kld_slot, d_kld_cur, d_kld_first, d_kld_child, d_kld_flags, d_kld_limit;
+  DevBuf<int2> d_kld_delta, d_kld_tiles, d_kld_counts;
+  PinnedBuf<int> h_kld;
+  std::vector<int> kld_limit_host;
+  double kld_limit_key[4] = { -1, -1, -1, -1 };  // pop_err, pop_z, min_samples, max_samples of the cached table
 
   // ---- motion model
   int odom_model = BPF_ODOM_MODEL_DIFF;
@@ -1023,6 +1035,124 @@ int launch_converged(bpf_engine* e)
   return BPF_OK;
 }
 
+// The KLD stop rule for the whole candidate stream [0, maxs) on the device (kernels_kld.hpp): re-draws the
+// stream with device-side keys, grows the histogram tree level by level and scans the leaf count.
+// Returns BPF_OK with *stop_out = stop count (or -1: no stop), *leaf_out / *bins_out at the final count;
+// *handled = false when a key does not fit the 64-bit packing or the tree is deeper than the level budget
+// (the caller then replays on the host as before).
+int kld_on_device(bpf_engine* e, DrawArgs A, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out)
+{
+  *handled = false;
+  const int n = maxs;
+  if (n >= (1 << 30))
+    return BPF_OK;  // element indices 2v + side are folded as 32-bit tags
+  // resampleLimit per leaf count, cached per parameter set (host libm, as the reference evaluates it)
+  if (e->kld_limit_key[0] != e->pop_err || e->kld_limit_key[1] != e->pop_z || e->kld_limit_key[2] != e->min_samples ||
+      e->kld_limit_key[3] != e->max_samples || (int)e->kld_limit_host.size() < n + 1)
+  {
+    e->kld_limit_host.resize((size_t)n + 1);
+    for (int k = 0; k <= n; ++k)
+      e->kld_limit_host[k] = resample_limit(k, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+    HIPCHK(e, e->d_kld_limit.reserve((size_t)n + 1));
+    HIPCHK(e, hipMemcpyAsync(e->d_kld_limit.p, e->kld_limit_host.data(), ((size_t)n + 1) * sizeof(int),
+                             hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->kld_limit_key[0] = e->pop_err;
+    e->kld_limit_key[1] = e->pop_z;
+    e->kld_limit_key[2] = e->min_samples;
+    e->kld_limit_key[3] = e->max_samples;
+  }
+  unsigned table = 1024;
+  while (table < 2u * (unsigned)n)
+    table <<= 1;
+  constexpr int kMaxLevels = 256;
+  const int tiles = blocks_for(n, kKldTile);
+  HIPCHK(e, e->d_kld_hkey.reserve(table));
+  HIPCHK(e, e->d_kld_htmin.reserve(table));
+  HIPCHK(e, e->d_kld_slot.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_cur.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_first.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_child.reserve((size_t)2 * n));
+  HIPCHK(e, e->d_kld_delta.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_counts.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_tiles.reserve((size_t)tiles));
+  HIPCHK(e, e->d_kld_flags.reserve(4 + kMaxLevels));
+  HIPCHK(e, e->h_kld.reserve(4 + kMaxLevels));
+  // the whole stream again, keys on the device only
+  A.m0 = 0;
+  A.m1 = n;
+  A.host_keys = nullptr;
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, A);
+  }
+  ProfScope ps(e, BPF_K_DRAW);
+  HIPCHK(e, hipMemsetAsync(e->d_kld_hkey.p, 0xFF, (size_t)table * sizeof(unsigned long long), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_htmin.p, 0x7F, (size_t)table * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_first.p, 0x7F, (size_t)n * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_child.p, 0x7F, (size_t)2 * n * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_flags.p, 0, (4 + kMaxLevels) * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_flags.p + 2, 0x7F, sizeof(int), e->stream));
+  KldArgs K{};
+  K.keys = e->d_keys.p;
+  K.n = n;
+  K.h_key = e->d_kld_hkey.p;
+  K.h_tmin = e->d_kld_htmin.p;
+  K.h_mask = table - 1;
+  K.slot = e->d_kld_slot.p;
+  K.cur = e->d_kld_cur.p;
+  K.first = e->d_kld_first.p;
+  K.child = e->d_kld_child.p;
+  K.delta = e->d_kld_delta.p;
+  K.flags = e->d_kld_flags.p;
+  K.limit = e->d_kld_limit.p;
+  const dim3 grid(blocks_for(n, 256)), block(256);
+  hipLaunchKernelGGL(k_kld_hash, grid, block, 0, e->stream, K);
+  hipLaunchKernelGGL(k_kld_init, grid, block, 0, e->stream, K);
+  hipLaunchKernelGGL(k_kld_root_first, dim3(1), dim3(1024), 0, e->stream, K);
+  int level = 0;
+  bool done = false;
+  while (!done && level < kMaxLevels)
+  {
+    const int batch = (level == 0) ? 32 : 16;
+    for (int q = 0; q < batch && level < kMaxLevels; ++q, ++level)
+    {
+      hipLaunchKernelGGL(k_kld_children, dim3(blocks_for(n, kKldBlock)), dim3(kKldBlock), 0, e->stream, K);
+      hipLaunchKernelGGL(k_kld_descend, dim3(blocks_for(n, kKldBlock)), dim3(kKldBlock), 0, e->stream, K,
+                         e->d_kld_flags.p + 4 + level);
+    }
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(e->h_kld.p, e->d_kld_flags.p, (4 + kMaxLevels) * sizeof(int), hipMemcpyDeviceToHost,
+                             e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->h_kld.p[0] != 0)
+      return BPF_OK;  // a key outside the packing range: not handled
+    done = e->h_kld.p[4 + level - 1] == 0;
+  }
+  if (getenv("BPF_DEBUG"))
+    fprintf(stderr, "[kld device] n %d levels %d done %d\n", n, level, (int)done);
+  if (!done)
+    return BPF_OK;  // deeper than the level budget: not handled
+  hipLaunchKernelGGL(k_kld_scan_tiles, dim3(tiles), dim3(256), 0, e->stream, (const int2*)e->d_kld_delta.p, n,
+                     e->d_kld_tiles.p);
+  hipLaunchKernelGGL(k_kld_scan_offsets, dim3(1), dim3(1024), 0, e->stream, e->d_kld_tiles.p, tiles);
+  hipLaunchKernelGGL(k_kld_scan_final, dim3(tiles), dim3(256), 0, e->stream, K, (const int2*)e->d_kld_tiles.p,
+                     e->d_kld_counts.p);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(e->h_kld.p, e->d_kld_flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const int stop = e->h_kld.p[2];
+  const int M = (stop >= 1 && stop <= n) ? stop : n;
+  int2 c;
+  HIPCHK(e, hipMemcpyAsync(&c, e->d_kld_counts.p + (M - 1), sizeof(int2), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  *stop_out = (stop >= 1 && stop <= n) ? stop : -1;
+  *leaf_out = c.x;
+  *bins_out = c.y;
+  *handled = true;
+  return BPF_OK;
+}
+
 // Spin on the generation word a kernel publishes in pinned host memory (kernels of ~10 us); false if it
 // takes implausibly long, and the caller falls back to a copy + stream synchronisation.
 bool wait_generation(bpf_engine* e, unsigned generation)
@@ -1053,6 +1183,11 @@ int resample_multinomial(bpf_engine* e)
   int window = std::max(1024, std::min(e->window_hint, maxs));
   e->resample_windows = 0;
   int cached_leaf = -1, cached_limit = 0;
+  e->kld_device_used = false;
+  bool device_declined = false;
+  // keep the host's first window short when the device tree can take over after it
+  if (window > 4096 && maxs - 4096 >= e->kld_device_min)
+    window = 4096;
   while (m0 < maxs && stop < 0)
   {
     const int m1 = std::min(maxs, m0 + window);
@@ -1069,6 +1204,28 @@ int resample_multinomial(bpf_engine* e)
     A.src_index = e->d_src_index.p;
     A.miss_flag = e->d_flags.p;
     A.sharded = 0;
+    // long stream ahead: either the first window found no stop, or the previous cycle ran to the end
+    const bool long_stream = (m0 > 0 || e->window_hint >= maxs) && maxs - m0 >= e->kld_device_min;
+    if (long_stream && !device_declined)
+    {
+      // no stop inside the first window and a long stream ahead (a spread cloud): the ordered replay moves
+      // to the device for the whole stream
+      bool handled = false;
+      int dstop = -1, dleaf = 0, dbins = 0;
+      int rc = kld_on_device(e, A, maxs, &handled, &dstop, &dleaf, &dbins);
+      if (rc != BPF_OK)
+        return rc;
+      if (handled)
+      {
+        e->resample_windows++;
+        stop = dstop;
+        e->kld_device_used = true;
+        e->kld_leaf = dleaf;
+        e->kld_bins = dbins;
+        break;
+      }
+      device_declined = true;  // key range or depth outside what the device tree takes: host replay as before
+    }
     const int wn = m1 - m0;
     // Keys go straight into pinned host memory and the last block publishes a generation number
     // there: the host polls that word instead of paying for a copy plus a stream synchronisation.
@@ -1854,6 +2011,7 @@ int bpf_pf_update_resample(bpf_engine* e)
   int rc = build_cdf(e, a.w.p, e->sample_count);
   if (rc != BPF_OK)
     return rc;
+  e->kld_device_used = false;
   rc = (e->resample_model == BPF_RESAMPLE_SYSTEMATIC) ? resample_systematic(e) : resample_multinomial(e);
   if (rc != BPF_OK)
     return rc;
@@ -1861,8 +2019,8 @@ int bpf_pf_update_resample(bpf_engine* e)
   SampleSet& b = e->sets[e->cur ^ 1];
   e->tile_sums_n = -1;
   e->cur ^= 1;
-  e->leaf_count = e->hist.leaf_count();
-  e->bin_count = e->hist.bin_count();
+  e->leaf_count = e->kld_device_used ? e->kld_leaf : e->hist.leaf_count();
+  e->bin_count = e->kld_device_used ? e->kld_bins : e->hist.bin_count();
   if (M <= 8192)
   {
     // small resampled set: weights 1/M and updateConverged in one single-block launch
@@ -1888,7 +2046,7 @@ int bpf_pf_update_resample(bpf_engine* e)
   // miss flag was copied? read it with the next fetch; report asynchronously via last_status
   e->last_status = BPF_OK;
   e->set_epoch++;
-  e->hist_matches_set = true;
+  e->hist_matches_set = !e->kld_device_used;  // the device tree leaves no host histogram behind
   return BPF_OK;
 }
 
@@ -1916,6 +2074,8 @@ int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out)
   out->w_diff = e->w_diff_last;
   out->last_status = e->last_status;
   out->resample_windows = e->resample_windows;
+  out->kld_on_device = e->kld_device_used ? 1 : 0;
+  out->reserved = 0;
   out->evals = e->evals_last;
   return BPF_OK;
 }
@@ -3122,6 +3282,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->window_enabled = value != 0;
   else if (option == BPF_OPT_COUNT_CELLS)
     e->count_cells = value != 0;
+  else if (option == BPF_OPT_KLD_DEVICE_MIN)
+    e->kld_device_min = value > 0 ? value : 0x7fffffff;
   else
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown option");
   return BPF_OK;

@@ -1,0 +1,339 @@
+// The KLD stop rule of resampleMultinomial on the device, for draw streams too long to replay on the
+// host (a spread cloud: no early stop, 10^5 keys).
+//
+// Reference (particle_filter.cpp:401-418, pf_kdtree.cpp:97-150): draw m's pose is inserted into the
+// histogram kd-tree and the loop stops as soon as  m + 1 > resampleLimit(leaf count).  In this fork every
+// tree node holds a bin key and counts as a leaf until the first different key is routed through it,
+// so the leaf count depends on the insertion order.  What makes it parallel:
+//
+//   * the tree after m insertions is the tree of the first m keys -- later keys only add descendants;
+//   * node v's split axis is fixed by the EARLIEST different key routed through it, and its child on
+//     either side is the earliest key on that side.  So the whole tree can be grown level by level
+//     from the complete key stream: every key that is not yet a node sits at some node v; per level
+//     one pass finds, per node, the earliest waiting key (atomicMin of draw indices), a second pass the
+//     earliest on each side; those become v's children, the rest step down.
+//   * v stops being a leaf exactly when its first child appears, i.e. at draw index first[v].  Hence
+//     leaf_count after draw m = #{nodes created <= m} - #{nodes whose first child was created <= m},
+//     a prefix sum over per-draw deltas, and the stop index is the first m with m + 1 > limit[leaf(m)].
+//
+// Repeated keys are folded first (hash table on the packed 64-bit key, atomicMin of the draw index):
+// only a key's first occurrence is a tree key, as in PFKDTree::insertNode (equal key: value += ...).
+#pragma once
+#include <climits>
+
+#include "device_types.hpp"
+
+namespace bpf
+{
+
+constexpr unsigned long long kKldEmpty = ~0ull;
+
+struct KldArgs
+{
+  const int* keys;              // [3 * n] bin keys in draw order (AoS)
+  int n;                        // draws in the stream
+  unsigned long long* h_key;    // hash table: packed key per slot (kKldEmpty = free)
+  int* h_tmin;                  // hash table: earliest draw index with that key
+  unsigned h_mask;              // table size - 1 (power of two)
+  int* slot;                    // [n] table slot of each draw
+  int* cur;                     // [n] node (draw index of its key) a waiting key currently sits at; -1: is a node / duplicate
+  int* first;                   // [n] per node: earliest key routed through it (INT_MAX: still a leaf)
+  int* child;                   // [2 * n] per node: earliest key on the low / high side
+  int2* delta;                  // [n] per draw: (leaf-count change, new-bin flag)
+  int* flags;                   // [0] keys out of packing range, [2] stop index
+  const int* limit;             // resampleLimit per leaf count, [0 .. n]
+};
+
+__device__ __forceinline__ bool kld_pack(const int* k, unsigned long long* out)
+{
+  const long long a = (long long)k[0] + (1 << 23), b = (long long)k[1] + (1 << 23), c = (long long)k[2] + (1 << 15);
+  if (a < 0 || a >= (1 << 24) - 1 || b < 0 || b >= (1 << 24) || c < 0 || c >= (1 << 16))
+    return false;
+  *out = ((unsigned long long)a << 40) | ((unsigned long long)b << 16) | (unsigned long long)c;
+  return true;
+}
+
+// atomicMin(base[a], i) for the threads of a block, combined in LDS first.  Near the root of the tree thousands
+// of keys wait at the same few nodes, and same-address atomics serialise in L2 (~80 ns each): a block folds
+// its keys per target element in an LDS hash table (tag = element index, value = min draw index) and sends one
+// atomic per distinct element; a key that finds no table slot in two probes goes to memory directly.
+constexpr int kKldBlock = 1024;
+constexpr int kKldCombine = 2048;
+
+__device__ __forceinline__ void block_atomic_min(int* base, unsigned a, int i, bool active, unsigned* s_tag, int* s_val)
+{
+  for (int s = threadIdx.x; s < kKldCombine; s += kKldBlock)
+  {
+    s_tag[s] = 0xFFFFFFFFu;
+    s_val[s] = INT_MAX;
+  }
+  __syncthreads();
+  if (active)
+  {
+    unsigned h = (a * 2654435761u) >> 21;  // 11 bits
+    bool placed = false;
+#pragma unroll
+    for (int probe = 0; probe < 2 && !placed; ++probe)
+    {
+      const unsigned prev = atomicCAS(&s_tag[h], 0xFFFFFFFFu, a);
+      if (prev == 0xFFFFFFFFu || prev == a)
+      {
+        atomicMin(&s_val[h], i);
+        placed = true;
+      }
+      h = (h + 1) & (kKldCombine - 1);
+    }
+    if (!placed)
+      atomicMin(&base[a], i);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < kKldCombine; s += kKldBlock)
+    if (s_tag[s] != 0xFFFFFFFFu)
+      atomicMin(&base[s_tag[s]], s_val[s]);
+}
+
+// pass 1: fold repeated keys; tmin[slot] = first draw with that key
+__global__ void k_kld_hash(const KldArgs A)
+{
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= A.n)
+    return;
+  unsigned long long pk;
+  if (!kld_pack(&A.keys[3 * (size_t)m], &pk))
+  {
+    atomicExch(&A.flags[0], 1);
+    A.slot[m] = 0;
+    return;
+  }
+  unsigned h = (unsigned)((pk * 0x9E3779B97F4A7C15ull) >> 32) & A.h_mask;
+  for (;;)
+  {
+    const unsigned long long prev = atomicCAS(&A.h_key[h], kKldEmpty, pk);
+    if (prev == kKldEmpty || prev == pk)
+      break;
+    h = (h + 1) & A.h_mask;
+  }
+  atomicMin(&A.h_tmin[h], m);
+  A.slot[m] = (int)h;
+}
+
+// pass 2: tree keys = first occurrences; all of them wait at the root (draw 0) and report to it
+__global__ void k_kld_init(const KldArgs A)
+{
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= A.n)
+    return;
+  const bool is_first = A.h_tmin[A.slot[m]] == m;
+  A.delta[m] = make_int2(is_first ? 1 : 0, is_first ? 1 : 0);
+  A.cur[m] = (is_first && m != 0) ? 0 : -1;
+}
+
+// the earliest key that waits at the root (one block)
+__global__ __launch_bounds__(1024) void k_kld_root_first(const KldArgs A)
+{
+  __shared__ int s_min[16];
+  int best = INT_MAX;
+  for (int m = threadIdx.x; m < A.n; m += 1024)
+    if (A.cur[m] == 0)
+    {
+      best = m;  // the first hit of a strided walk is this thread's smallest
+      break;
+    }
+  for (int o = 32; o > 0; o >>= 1)
+    best = min(best, __shfl_xor(best, o, 64));
+  if ((threadIdx.x & 63) == 0)
+    s_min[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    for (int w = 1; w < 16; ++w)
+      best = min(best, s_min[w]);
+    if (best != INT_MAX)
+      A.first[0] = best;
+  }
+}
+
+__device__ __forceinline__ int kld_side(const int* keys, int v, int f, int i)
+{
+  // split axis of v: largest |delta| between v's key and the first different key through it, earliest
+  // axis on ties (pf_kdtree.cpp:133-146); a key goes to the high side if it is greater on that axis
+  const int* kv = &keys[3 * (size_t)v];
+  const int* kf = &keys[3 * (size_t)f];
+  int best = 0, pv = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+  {
+    const int s = abs(kf[d] - kv[d]);
+    if (s > best)
+    {
+      best = s;
+      pv = d;
+    }
+  }
+  return keys[3 * (size_t)i + pv] > kv[pv] ? 1 : 0;
+}
+
+// level, first half: the earliest waiting key on each side of every node
+__global__ __launch_bounds__(kKldBlock) void k_kld_children(const KldArgs A)
+{
+  __shared__ unsigned s_tag[kKldCombine];
+  __shared__ int s_val[kKldCombine];
+  const int i = blockIdx.x * kKldBlock + threadIdx.x;
+  const int v = (i < A.n) ? A.cur[i] : -1;
+  const bool waiting = v >= 0;
+  unsigned a = 0;
+  if (waiting)
+    a = 2u * (unsigned)v + (unsigned)kld_side(A.keys, v, A.first[v], i);
+  block_atomic_min(A.child, a, i, waiting, s_tag, s_val);
+}
+
+// level, second half: that key becomes the child node; the others step down to it and report
+// `waiting` is set when a key is still not a node after this level (one word per level)
+__global__ __launch_bounds__(kKldBlock) void k_kld_descend(const KldArgs A, int* waiting)
+{
+  __shared__ unsigned s_tag[kKldCombine];
+  __shared__ int s_val[kKldCombine];
+  const int i = blockIdx.x * kKldBlock + threadIdx.x;
+  const int v = (i < A.n) ? A.cur[i] : -1;
+  bool still = false;
+  int c = 0;
+  if (v >= 0)
+  {
+    const int f = A.first[v];
+    const int side = kld_side(A.keys, v, f, i);
+    c = A.child[2 * (size_t)v + side];
+    if (c == i)
+    {
+      A.cur[i] = -1;  // i is a node now
+      if (f == i)
+        A.delta[i].x = 0;  // its creation ends the parent's time as a leaf: +1 - 1
+    }
+    else
+    {
+      A.cur[i] = c;
+      still = true;
+    }
+  }
+  block_atomic_min(A.first, (unsigned)c, i, still, s_tag, s_val);
+  if (still)
+    *waiting = 1;  // every writer stores the same value
+}
+
+// inclusive scan of delta (int2) in tiles of 2048, three launches
+constexpr int kKldTile = 2048;
+
+__global__ __launch_bounds__(256) void k_kld_scan_tiles(const int2* __restrict__ delta, int n, int2* __restrict__ tile_sums)
+{
+  __shared__ int2 s_w[4];
+  const int base = blockIdx.x * kKldTile;
+  int2 acc = make_int2(0, 0);
+  for (int j = threadIdx.x; j < kKldTile; j += 256)
+    if (base + j < n)
+    {
+      const int2 d = delta[base + j];
+      acc.x += d.x;
+      acc.y += d.y;
+    }
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    acc.x += __shfl_xor(acc.x, o, 64);
+    acc.y += __shfl_xor(acc.y, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0)
+    s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    tile_sums[blockIdx.x] = make_int2(s_w[0].x + s_w[1].x + s_w[2].x + s_w[3].x, s_w[0].y + s_w[1].y + s_w[2].y + s_w[3].y);
+}
+
+// one block: exclusive scan of the tile sums in place
+__global__ __launch_bounds__(1024) void k_kld_scan_offsets(int2* tile_sums, int tiles)
+{
+  __shared__ int2 s_part[1024];
+  const int tid = threadIdx.x;
+  const int per = (tiles + 1023) / 1024;
+  const int lo = min(tid * per, tiles), hi = min(lo + per, tiles);
+  int2 sum = make_int2(0, 0);
+  for (int i = lo; i < hi; ++i)
+  {
+    sum.x += tile_sums[i].x;
+    sum.y += tile_sums[i].y;
+  }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1)
+  {
+    const int2 v = (tid >= o) ? s_part[tid - o] : make_int2(0, 0);
+    __syncthreads();
+    s_part[tid].x += v.x;
+    s_part[tid].y += v.y;
+    __syncthreads();
+  }
+  int2 run = make_int2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);
+  for (int i = lo; i < hi; ++i)
+  {
+    const int2 t = tile_sums[i];
+    tile_sums[i] = run;
+    run.x += t.x;
+    run.y += t.y;
+  }
+}
+
+// per tile: inclusive scan -> (leaf count, bin count) after every draw, and the stop test
+// (particle_filter.cpp:416: sample_count > resampleLimit(leaf_count), sample_count = m + 1)
+__global__ __launch_bounds__(256) void k_kld_scan_final(const KldArgs A, const int2* __restrict__ tile_offsets,
+                                                        int2* __restrict__ counts)
+{
+  __shared__ int2 s_w[4];
+  constexpr int per = kKldTile / 256;
+  const int base = blockIdx.x * kKldTile + threadIdx.x * per;
+  int2 v[per];
+  int2 sum = make_int2(0, 0);
+#pragma unroll
+  for (int j = 0; j < per; ++j)
+  {
+    v[j] = (base + j < A.n) ? A.delta[base + j] : make_int2(0, 0);
+    sum.x += v[j].x;
+    sum.y += v[j].y;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int2 incl = sum;
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int ux = __shfl_up(incl.x, o, 64), uy = __shfl_up(incl.y, o, 64);
+    if (lane >= o)
+    {
+      incl.x += ux;
+      incl.y += uy;
+    }
+  }
+  if (lane == 63)
+    s_w[wave] = incl;
+  __syncthreads();
+  int2 run = tile_offsets[blockIdx.x];
+  for (int q = 0; q < wave; ++q)
+  {
+    run.x += s_w[q].x;
+    run.y += s_w[q].y;
+  }
+  run.x += incl.x - sum.x;
+  run.y += incl.y - sum.y;
+  int stop = INT_MAX;
+#pragma unroll
+  for (int j = 0; j < per; ++j)
+  {
+    const int m = base + j;
+    if (m < A.n)
+    {
+      run.x += v[j].x;
+      run.y += v[j].y;
+      counts[m] = run;
+      if (m + 1 > A.limit[run.x] && stop == INT_MAX)
+        stop = m + 1;
+    }
+  }
+  if (stop != INT_MAX)
+    atomicMin(&A.flags[2], stop);
+}
+
+}  // namespace bpf

@@ -165,7 +165,9 @@ enum
 {
   BPF_OPT_CDF_SERIAL = 0,
   BPF_OPT_COUNT_CELLS = 1,
-  BPF_OPT_WINDOW_PATH = 2   /* default 0: 1 allows the LDS-window scoring kernels (device-side switch) */
+  BPF_OPT_WINDOW_PATH = 2,  /* default 0: 1 allows the LDS-window scoring kernels (device-side switch) */
+  BPF_OPT_KLD_DEVICE_MIN = 3 /* default 8192: candidate draws left after the first window from which the KLD stop
+                              * rule (ordered kd-tree replay) runs on the device instead of the host; 0 = never */
 };
 int bpf_set_option(bpf_engine* e, int option, int value);
 /* cells visited by calcRange walks since the last reset (BPF_OPT_COUNT_CELLS) */
@@ -184,6 +186,8 @@ typedef struct
   int last_status;        /* BPF_* of the last update_sensor / update_resample */
   int resample_windows;   /* candidate-draw windows used by the last multinomial resample */
   long long evals;        /* particle-beam evaluations of the last sensor update */
+  int kld_on_device;      /* 1 if the last multinomial resample ran the KLD stop rule on the device */
+  int reserved;
 } bpf_pf_state;
 int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out);
 

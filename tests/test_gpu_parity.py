@@ -143,6 +143,62 @@ def test_update_resample_matches_oracle(engine, orc, cloud, n, resampler, serial
     assert st1.last_status == 0
 
 
+@pytest.mark.parametrize("cloud,n,pop", [("spread", 3000, None), ("converged", 3000, None), ("mixture", 20000, None),
+                                         ("spread", 30000, (0.0025, 0.9975)), ("mixture", 9000, (0.05, 0.99))])
+def test_kld_stop_rule_on_device_matches_oracle(engine, orc, cloud, n, pop):
+    """The level-synchronous device build of the histogram tree (long draw streams) against the oracle's serial
+    insertion: stop count, leaf count, bin count, poses and RNG state exact.  BPF_OPT_KLD_DEVICE_MIN = 1 sends
+    even these small sets through it; serial CDF so that no draw sits on a summation-order knife edge."""
+    import badger_amcl_amd.pf as hpf
+    sc_ = Scenario(orc, size=400, n=n, beams=61, cloud=cloud)
+    engine.set_option(hpf.OPT_CDF_SERIAL, 1)
+    engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 1)
+    try:
+        m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf", min_samples=100, seed=5)
+        if pop:
+            pf.setPopulationSizeParameters(*pop)
+        results = []
+        for cycle in range(2):  # the second cycle starts from the window hint the first one left
+            sc.updateSensor(pf, data)
+            before = pf.getCurrentSet()
+            st0 = pf.getState()
+            rng0 = pf.getRngState()
+            pf.updateResample()
+            after = pf.getCurrentSet()
+            st1 = pf.getState()
+            opf = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0)
+            opf.pf.rng = rng0
+            opf.set_samples(before.samples, leaf_count=st0.leaf_count)
+            opf.pf.w_slow, opf.pf.w_fast = st0.w_slow, st0.w_fast
+            if pop:
+                opf.set_population_size_parameters(*pop)
+            out = opf.update_resample()
+            assert out.status == 0
+            if n <= 4096 or out.sample_count > 4096:  # otherwise the host's first window already found the stop
+                assert st1.kld_on_device == 1
+            assert st1.sample_count == out.sample_count, cycle
+            assert st1.leaf_count == out.leaf_count and st1.bin_count == out.node_count
+            M = out.sample_count
+            assert np.array_equal(after.samples[:, :3], opf.samples[:M, :3])
+            assert pf.getRngState() == opf.pf.rng
+            results.append(M)
+            # continue from the whole cloud again so that the second cycle is a long stream too
+            pf.initWithSamples(sc_.samples)
+        # cluster statistics after a device-side stop: the host tree is rebuilt on demand
+        sc.updateSensor(pf, data)
+        pf.updateResample()
+        cur = pf.getCurrentSet().samples
+        t = orc.KDTree()
+        for k in range(cur.shape[0]):
+            t.insert_pose(cur[k, :3], cur[k, 3])
+        want = t.cluster_stats(cur, n)
+        cnt, mean, cov = pf.computeClusterStats()
+        assert cnt == want["n"] and np.array_equal(mean, want["set_mean"])
+    finally:
+        engine.set_option(hpf.OPT_CDF_SERIAL, 0)
+        engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 8192)
+
+
 def test_resample_kld_parameters_and_second_cycle(engine, orc):
     """Launch-file KLD parameters (kld_err .0025 passed as pop_err, kld_z .9975 as pop_z) and two
     full update+resample cycles, the second starting from the resampled set."""
