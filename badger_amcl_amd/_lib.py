@@ -107,6 +107,7 @@ SIGNATURES = {
     "bpf_kld_reset": (C.c_int, [_vp]),
     "bpf_kld_feed": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "bpf_kld_feed_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _ip]),
+    "bpf_kld_stop_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
     "bpf_kld_leaf_count": (C.c_int, [_vp, _ip, _ip]),
     "bpf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "bpf_profile_reset": (C.c_int, [_vp]),

@@ -1035,12 +1035,12 @@ int launch_converged(bpf_engine* e)
   return BPF_OK;
 }
 
-// The KLD stop rule for the whole candidate stream [0, maxs) on the device (kernels_kld.hpp): re-draws the
-// stream with device-side keys, grows the histogram tree level by level and scans the leaf count.
+// The KLD stop rule for the whole candidate stream [0, maxs) on the device (kernels_kld.hpp), keys in
+// e->d_keys (AoS): grows the histogram tree level by level and scans the leaf count.
 // Returns BPF_OK with *stop_out = stop count (or -1: no stop), *leaf_out / *bins_out at the final count;
 // *handled = false when a key does not fit the 64-bit packing or the tree is deeper than the level budget
 // (the caller then replays on the host as before).
-int kld_on_device(bpf_engine* e, DrawArgs A, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out)
+int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out)
 {
   *handled = false;
   const int n = maxs;
@@ -1078,14 +1078,6 @@ int kld_on_device(bpf_engine* e, DrawArgs A, int maxs, bool* handled, int* stop_
   HIPCHK(e, e->d_kld_tiles.reserve((size_t)tiles));
   HIPCHK(e, e->d_kld_flags.reserve(4 + kMaxLevels));
   HIPCHK(e, e->h_kld.reserve(4 + kMaxLevels));
-  // the whole stream again, keys on the device only
-  A.m0 = 0;
-  A.m1 = n;
-  A.host_keys = nullptr;
-  {
-    ProfScope ps(e, BPF_K_DRAW);
-    hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, A);
-  }
   ProfScope ps(e, BPF_K_DRAW);
   HIPCHK(e, hipMemsetAsync(e->d_kld_hkey.p, 0xFF, (size_t)table * sizeof(unsigned long long), e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_kld_htmin.p, 0x7F, (size_t)table * sizeof(int), e->stream));
@@ -1151,6 +1143,19 @@ int kld_on_device(bpf_engine* e, DrawArgs A, int maxs, bool* handled, int* stop_
   *bins_out = c.y;
   *handled = true;
   return BPF_OK;
+}
+
+// the whole candidate stream [0, maxs) again with the keys on the device only, then the tree
+int kld_on_device(bpf_engine* e, DrawArgs A, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out)
+{
+  A.m0 = 0;
+  A.m1 = maxs;
+  A.host_keys = nullptr;
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(maxs, 256)), dim3(256), 0, e->stream, A);
+  }
+  return kld_tree_on_device(e, maxs, handled, stop_out, leaf_out, bins_out);
 }
 
 // Spin on the generation word a kernel publishes in pinned host memory (kernels of ~10 us); false if it
@@ -3259,6 +3264,27 @@ int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_ke
   if (!wait_generation(e, generation))
     HIPCHK(e, hipStreamSynchronize(e->stream));
   return bpf_kld_feed(e, e->h_keys.p, 0, n_keys, n_keys, first_draw_index, stop_count_out);
+}
+
+int bpf_kld_stop_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int* handled_out,
+                     int* stop_count_out, int* leaf_count_out, int* bin_count_out)
+{
+  if (!e || !window_dev || !handled_out || !stop_count_out || !leaf_count_out || !bin_count_out || stride < n_keys ||
+      n_keys <= 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, e->d_keys.reserve((size_t)n_keys * 3));
+  hipLaunchKernelGGL(k_window_keys_to_aos, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
+                     static_cast<const long long*>(window_dev), stride, n_keys, e->d_keys.p);
+  HIPCHK(e, hipGetLastError());
+  bool handled = false;
+  *stop_count_out = -1;
+  *leaf_count_out = *bin_count_out = 0;
+  int rc = kld_tree_on_device(e, n_keys, &handled, stop_count_out, leaf_count_out, bin_count_out);
+  *handled_out = handled ? 1 : 0;
+  return rc;
 }
 
 int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out)

@@ -837,6 +837,18 @@ __global__ void k_publish_window_keys(const long long* __restrict__ window, int 
   publish_when_last(done_counter, host_done, generation);
 }
 
+// rows 3..5 of an int64 draw window -> int key triples (AoS) on the device
+__global__ void k_window_keys_to_aos(const long long* __restrict__ window, int stride, int n, int* __restrict__ keys)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n)
+  {
+    keys[3 * (size_t)q] = (int)window[(size_t)3 * stride + q];
+    keys[3 * (size_t)q + 1] = (int)window[(size_t)4 * stride + q];
+    keys[3 * (size_t)q + 2] = (int)window[(size_t)5 * stride + q];
+  }
+}
+
 __global__ void k_pose_keys(ParticlesDev p, int n, int* __restrict__ keys)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -97,6 +97,15 @@ class HipShardBackend:
                                                  C.byref(stop)))
         return stop.value
 
+    kld_device_min = 8192  # draws left after the first window from which the device tree takes the whole stream
+
+    def kld_stop_window(self, window, n):
+        """Stop rule for the whole stream on the device: (handled, stop or -1, leaf_count, bin_count)."""
+        h, stop, leaf, bins = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.e.check(self.e.lib.bpf_kld_stop_dev(self.e.h, C.c_void_p(window.data_ptr()), window.shape[1], n,
+                                                 C.byref(h), C.byref(stop), C.byref(leaf), C.byref(bins)))
+        return bool(h.value), stop.value, leaf.value, bins.value
+
     def kld_counts(self):
         a, b = C.c_int(), C.c_int()
         self.e.check(self.e.lib.bpf_kld_leaf_count(self.e.h, C.byref(a), C.byref(b)))
@@ -203,7 +212,28 @@ class ShardedFilter:
         win = max(1024, min(self.window_hint, self.max_global))
         self.windows_used = 0
         windows = []
+        device_counts = None
+        device_min = b.kld_device_min
+        if win > 4096 and self.max_global - 4096 >= device_min:
+            win = 4096  # keep the host's first window short when the device tree can take over after it
         while m0 < self.max_global and stop < 0:
+            if m0 > 0 and self.max_global - m0 >= device_min:
+                # no stop in the first window and a long stream ahead (a spread cloud): one window with every
+                # remaining candidate, and the ordered kd-tree replay runs on the device (every rank, redundantly)
+                whole = self._windows.get("whole")
+                if whole is None:
+                    whole = torch.zeros((6, self.max_global), dtype=torch.int64, device=self.device)
+                    self._windows["whole"] = whole
+                b.draw_window(rng, 0, self.max_global, sums, sums_are_totals, self.rank, W, whole, self.flags)
+                self._all_reduce_sum(whole)
+                handled, dstop, dleaf, dbins = b.kld_stop_window(whole, self.max_global)
+                self.windows_used += 1
+                if handled:
+                    stop = dstop
+                    windows = [(0, self.max_global, whole)]
+                    device_counts = (dleaf, dbins)
+                    break
+                device_min = 1 << 62  # this stream is outside what the device tree takes: host replay
             m1 = min(self.max_global, m0 + win)
             cnt = m1 - m0
             window = self._windows.get((cnt, len(windows)))
@@ -218,7 +248,7 @@ class ShardedFilter:
             m0 = m1
             win *= 4
         M = stop if stop > 0 else self.max_global
-        leaf, bins = b.kld_counts()
+        leaf, bins = device_counts if device_counts is not None else b.kld_counts()
         lo, hi = (M * self.rank) // W, (M * (self.rank + 1)) // W
         if len(windows) == 1 and M <= 8192:
             # the common case: one window, small set -> adopt + weights + updateConverged in one launch

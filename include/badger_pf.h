@@ -328,6 +328,12 @@ int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride
  * generation word the host spins on (no D2H copy call, no stream synchronisation), then the replay runs. */
 int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int first_draw_index,
                      int* stop_count_out);
+/* the stop rule for a WHOLE candidate stream (draws 0 .. n_keys-1, keys in rows 3..5 of the device window)
+ * evaluated on the device (level-synchronous build of the same kd-tree).
+ * *handled_out = 0 when a key does not fit the 64-bit packing or the tree is deeper than 256 levels: feed the
+ * stream through bpf_kld_feed_dev instead.  *stop_count_out = -1: no stop up to n_keys. */
+int bpf_kld_stop_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int* handled_out,
+                     int* stop_count_out, int* leaf_count_out, int* bin_count_out);
 int bpf_kld_leaf_count(bpf_engine* e, int* leaf_count_out, int* bin_count_out);
 
 /* ------------------------------------------------------------------ wire formats

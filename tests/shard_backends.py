@@ -135,6 +135,11 @@ class OracleShardBackend:
     def kld_feed_window(self, window, n, first):
         return self.kld_feed(window[3:6].contiguous(), n, first)
 
+    kld_device_min = 1 << 62  # the CPU test backend has no device tree: always the ordered host replay
+
+    def kld_stop_window(self, window, n):
+        return False, -1, 0, 0
+
     def kld_counts(self):
         return self.tree.leaf_count(), self.tree.node_count()
 

@@ -25,13 +25,13 @@ ODOM = (2, 0.05, 0.04, 0.03, 0.02, 0.0)                         # diff-corrected
 ODATA = ((1.0, 2.0, 0.3), (0.03, -0.01, 0.02), (0.03, 0.01, 0.02))  # pose, delta, absolute motion
 
 
-def _scenario():
+def _scenario(cloud="converged"):
     from oracle import pyoracle as orc
     from scenario import Scenario
-    return orc, Scenario(orc, size=400, n=6000, beams=181, cloud="converged")
+    return orc, Scenario(orc, size=400, n=6000, beams=181, cloud=cloud)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, cloud, device_min):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir):
     import badger_amcl_amd as bpf
     from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
     from scenario import Scenario
-    orc, sc = _scenario()
+    orc, sc = _scenario(cloud)
     n = sc.samples.shape[0]
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     e = bpf.Engine(0)
@@ -52,6 +52,7 @@ def _worker(rank, world, port, out_dir):
     shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
     m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
     b = HipShardBackend(e, scn, pf, torch.device("cuda", 0))
+    b.kld_device_min = device_min
     sf = ShardedFilter(b, dist, first_window=1024)
     od = bpf.Odom(e)
     od.setModel(*ODOM)
@@ -64,22 +65,25 @@ def _worker(rank, world, port, out_dir):
         st = sf.state()
         recs.append(dict(w=w_after, samples=pf.getCurrentSet().samples.copy(), M=st.sample_count, leaf=st.leaf_count,
                          bins=st.bin_count, rng=pf.getRngState(), conv=st.converged, miss=st.cdf_miss,
-                         w_slow=st.w_slow))
+                         w_slow=st.w_slow, windows=st.windows))
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(recs, dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
     e.close()
 
 
-def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path):
+@pytest.mark.parametrize("cloud,device_min", [("converged", 8192), ("spread", 512)])
+def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min):
+    """converged: early KLD stop inside the first window (host replay).  spread with a low device threshold: no
+    stop in the first window, so one window with the whole stream follows and the stop rule runs on the device."""
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), cloud, device_min), nprocs=2, join=True)
     recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
 
     import badger_amcl_amd as bpf
-    orc, sc = _scenario()
+    orc, sc = _scenario(cloud)
     n = sc.samples.shape[0]
     e = bpf.Engine(0)
     m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
@@ -102,4 +106,6 @@ def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path):
         merged = np.concatenate([r0["samples"], r1["samples"]])
         assert np.array_equal(merged[:, :3], cur.samples[:, :3])
         assert np.all(merged[:, 3] == 1.0 / st.sample_count)
+    if cloud == "spread":
+        assert recs[0][0]["windows"] == 2 and recs[0][0]["M"] > 1024  # first window + the whole-stream window
     e.close()
