@@ -107,6 +107,11 @@ SIGNATURES = {
     "bpf_kld_reset": (C.c_int, [_vp]),
     "bpf_kld_feed": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "bpf_kld_feed_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _ip]),
+    "bpf_pf_resample_limit": (C.c_int, [_vp, C.c_int, _ip]),
+    "bpf_shard_systematic_window_dev": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp,
+                                                  C.c_int, _vp]),
+    "bpf_kld_insert": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "bpf_kld_insert_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "bpf_kld_stop_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
     "bpf_kld_leaf_count": (C.c_int, [_vp, _ip, _ip]),
     "bpf_profile_enable": (C.c_int, [_vp, C.c_int]),

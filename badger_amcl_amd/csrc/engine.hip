@@ -231,6 +231,7 @@ struct bpf_engine
   unsigned done_generation = 0;
   bool zero_copy_keys = true;
   PinnedBuf<double> h_targets;
+  hipEvent_t targets_read = nullptr;  // recorded after the sharded systematic window kernel
   PinnedBuf<int> h_flags;
   PinnedBuf<FilterScalars> h_scalars;
   PinnedBuf<double4> h_aos;
@@ -1432,6 +1433,8 @@ void bpf_destroy(bpf_engine* e)
     if (s.done)
       (void)hipEventDestroy(s.done);
   }
+  if (e->targets_read)
+    (void)hipEventDestroy(e->targets_read);
   for (auto ev : e->ev_start)
     (void)hipEventDestroy(ev);
   for (auto ev : e->ev_stop)
@@ -3264,6 +3267,101 @@ int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_ke
   if (!wait_generation(e, generation))
     HIPCHK(e, hipStreamSynchronize(e->stream));
   return bpf_kld_feed(e, e->h_keys.p, 0, n_keys, n_keys, first_draw_index, stop_count_out);
+}
+
+int bpf_pf_resample_limit(bpf_engine* e, int leaf_count, int* count_out)
+{
+  if (!e || !count_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  *count_out = resample_limit(leaf_count, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+  return BPF_OK;
+}
+
+int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int count, const void* sums_dev,
+                                    int sums_are_totals, int rank, int world, void* window_dev, int stride,
+                                    void* flags_dev)
+{
+  if (!e || !e->have_pf || !sums_dev || !window_dev || !flags_dev || count <= 0 || stride < count || rank < 0 ||
+      rank >= world)
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad systematic window arguments") : BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, e->h_targets.reserve((size_t)std::max(count, e->max_samples)));
+  // the reference's serial chain (particle_filter.cpp:337-341): target += delta, -= 1 once it passes 1
+  const uint64_t st = lcg_skip_host(rng_state48 & ((1ull << 48) - 1), 1, e->jump);
+  double t = std::ldexp((double)st, -48);
+  const double delta = 1.0 / count;
+  if (e->targets_read)  // a previous window kernel may still be reading the pinned targets
+    HIPCHK(e, hipEventSynchronize(e->targets_read));
+  for (int i = 0; i < count; ++i)
+  {
+    e->h_targets.p[i] = t;
+    t += delta;
+    if (t > 1.0)
+      t -= 1.0;
+  }
+  WindowArgs A{};
+  A.src = e->sets[e->cur].dev();
+  A.n_src = e->sample_count;
+  A.cdf = e->d_cdf.p;
+  A.sums = static_cast<const double*>(sums_dev);
+  A.sums_are_totals = sums_are_totals;
+  A.rank = rank;
+  A.world = world;
+  A.m0 = 0;
+  A.m1 = count;
+  A.rng_state = 0;
+  A.jump = e->jump;
+  A.window = static_cast<long long*>(window_dev);
+  A.stride = stride;
+  A.flags = static_cast<int*>(flags_dev);
+  A.targets = e->h_targets.p;
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream, A);
+  }
+  HIPCHK(e, hipGetLastError());
+  if (!e->targets_read)
+    HIPCHK(e, hipEventCreateWithFlags(&e->targets_read, hipEventDisableTiming));
+  HIPCHK(e, hipEventRecord(e->targets_read, e->stream));
+  return BPF_OK;
+}
+
+int bpf_kld_insert(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys)
+{
+  if (!e || !keys || stride < n_keys)
+    return BPF_ERR_INVALID_ARGUMENT;
+  const long long* k64 = static_cast<const long long*>(keys);
+  const int* k32 = static_cast<const int*>(keys);
+  for (int q = 0; q < n_keys; ++q)
+  {
+    int k[3];
+    for (int d = 0; d < 3; ++d)
+      k[d] = keys_are_int64 ? (int)k64[(size_t)d * stride + q] : k32[(size_t)d * stride + q];
+    if (e->seen.first_time(k[0], k[1], k[2]))
+      e->hist.insert(k[0], k[1], k[2]);
+  }
+  return BPF_OK;
+}
+
+int bpf_kld_insert_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys)
+{
+  if (!e || !window_dev || stride < n_keys || n_keys <= 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, e->h_keys.reserve((size_t)n_keys * 3));
+  const unsigned generation = ++e->done_generation;
+  hipLaunchKernelGGL(k_publish_window_keys, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
+                     static_cast<const long long*>(window_dev), stride, n_keys, e->h_keys.p,
+                     reinterpret_cast<unsigned*>(e->d_flags.p + 4), reinterpret_cast<volatile unsigned*>(e->h_done.p),
+                     generation);
+  HIPCHK(e, hipGetLastError());
+  if (!wait_generation(e, generation))
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  return bpf_kld_insert(e, e->h_keys.p, 0, n_keys, n_keys);
 }
 
 int bpf_kld_stop_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int* handled_out,

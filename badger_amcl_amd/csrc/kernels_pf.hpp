@@ -672,6 +672,7 @@ struct WindowArgs
   long long* window;     // [6][stride]
   int stride;
   int* flags;
+  const double* targets; // systematic resampling: r of draw m is targets[m] (nullptr: the drand48 stream)
 };
 
 __global__ void k_draw_window(const WindowArgs A)
@@ -695,8 +696,14 @@ __global__ void k_draw_window(const WindowArgs A)
   for (int r = 0; r < A.rank; ++r)
     offset += A.sums_are_totals ? A.sums[r] / T : A.sums[r];
   const double top = offset + (A.sums_are_totals ? A.sums[A.rank] / T : A.sums[A.rank]);
-  const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
-  const double r = ldexp((double)xs, -48);
+  double r;
+  if (A.targets != nullptr)
+    r = A.targets[m];
+  else
+  {
+    const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
+    r = ldexp((double)xs, -48);
+  }
   const bool last = A.rank == A.world - 1;
   const bool mine = (r >= offset) && (r < top || last);
   long long out[6] = { 0, 0, 0, 0, 0, 0 };

@@ -207,7 +207,13 @@ class ParticleFilter:
         engine.check(engine.lib.bpf_pf_create(engine.h, min_samples, max_samples, alpha_slow, alpha_fast,
                                               global_localization_convergence_threshold))
 
+    resample_model = PF_RESAMPLE_MULTINOMIAL
+
     def setResampleModel(self, model):
+        self.resample_model = int(model)
+        self._setResampleModel(model)
+
+    def _setResampleModel(self, model):
         self.e.check(self.e.lib.bpf_pf_set_resample_model(self.e.h, model))
 
     def setPopulationSizeParameters(self, pop_err, pop_z):

@@ -82,6 +82,11 @@ class HipShardBackend:
     def kld_reset(self):
         self.e.check(self.e.lib.bpf_kld_reset(self.e.h))
 
+    def kld_insert(self, keys_cpu, n):
+        k = keys_cpu.numpy()
+        assert k.dtype == np.int64 and k.flags.c_contiguous
+        self.e.check(self.e.lib.bpf_kld_insert(self.e.h, k.ctypes.data_as(C.c_void_p), 1, k.shape[1], n))
+
     def kld_feed(self, keys_cpu, n, first):
         stop = C.c_int(-1)
         k = keys_cpu.numpy()
@@ -96,6 +101,30 @@ class HipShardBackend:
         self.e.check(self.e.lib.bpf_kld_feed_dev(self.e.h, C.c_void_p(window.data_ptr()), window.shape[1], n, first,
                                                  C.byref(stop)))
         return stop.value
+
+    def resample_model(self):
+        return self.pf.resample_model
+
+    def resample_limit(self, leaf_count):
+        out = C.c_int()
+        self.e.check(self.e.lib.bpf_pf_resample_limit(self.e.h, int(leaf_count), C.byref(out)))
+        return out.value
+
+    def systematic_window(self, rng, count, sums, sums_are_totals, rank, world, window, flags):
+        e = self.e
+        e.check(e.lib.bpf_shard_systematic_window_dev(e.h, C.c_uint64(rng), count, C.c_void_p(sums.data_ptr()),
+                                                      int(sums_are_totals), rank, world,
+                                                      C.c_void_p(window.data_ptr()), window.shape[1],
+                                                      C.c_void_p(flags.data_ptr())))
+
+    def kld_insert_window(self, window, n):
+        self.e.check(self.e.lib.bpf_kld_insert_dev(self.e.h, C.c_void_p(window.data_ptr()), window.shape[1], n))
+
+    def local_pose_keys(self):
+        """int64 [3, n_local] histogram keys of the local poses (floor(pose / cell), pf_kdtree.cpp:52-54)."""
+        s = self.pf.getCurrentSet().samples
+        k = np.stack([np.floor(s[:, 0] / 0.5), np.floor(s[:, 1] / 0.5), np.floor(s[:, 2] / (10 * np.pi / 180))])
+        return torch.from_numpy(k.astype(np.int64)).to(self.device)
 
     kld_device_min = 8192  # draws left after the first window from which the device tree takes the whole stream
 
@@ -165,6 +194,10 @@ class ShardedFilter:
         self.leaf_count = self.bin_count = 0
         self.windows_used = 0
         self.totals = None  # per-shard weight totals of the last update_sensor (None: weights changed since)
+        if backend.resample_model() == 1:
+            # the systematic resampler sizes the new set from the leaf count of the CURRENT set's tree, which the
+            # reference builds when the set is created (not after motion updates): take it now
+            self._global_leaf_count()
 
     # ---- collectives (device tensors with nccl; staged through the host only for gloo + GPU)
     def _all_gather(self, t):
@@ -198,9 +231,63 @@ class ShardedFilter:
         self.totals = self._all_gather(self.b.local_total())
         self.b.normalize(self.totals, self.sample_count)
 
+    def _global_leaf_count(self):
+        """Leaf count of the kd-tree of the whole current set (what set_a->kdtree->getLeafCount() is for the
+        reference's systematic resampler): known after a resample, otherwise built once from all shards' keys."""
+        if self.leaf_count > 0:
+            return self.leaf_count
+        b = self.b
+        pad = max(self.counts)
+        mine = torch.zeros((3, pad), dtype=torch.int64, device=self.device)
+        k = b.local_pose_keys()
+        mine[:, :k.shape[1]] = k
+        allk = self._all_gather(mine.reshape(-1)).reshape(self.world, 3, pad).cpu()
+        b.kld_reset()
+        for r in range(self.world):
+            if self.counts[r]:
+                b.kld_insert(allk[r, :, :self.counts[r]].contiguous(), self.counts[r])
+        self.leaf_count, self.bin_count = b.kld_counts()
+        return self.leaf_count
+
+    # ---- Seam B, systematic (particle_filter.cpp:269-354, w_diff == 0)
+    def _update_resample_systematic(self):
+        b, W = self.b, self.world
+        count = b.resample_limit(self._global_leaf_count())
+        b.build_cdf(self.flags)
+        if self.totals is not None:
+            sums, sums_are_totals = self.totals, True
+        else:
+            sums, sums_are_totals = self._all_gather(b.local_sum()), False
+        rng = b.rng_state()
+        window = self._windows.get((count, "sys"))
+        if window is None:
+            window = torch.zeros((6, count), dtype=torch.int64, device=self.device)
+            self._windows[(count, "sys")] = window
+        b.systematic_window(rng, count, sums, sums_are_totals, self.rank, W, window, self.flags)
+        self._all_reduce_sum(window)
+        b.kld_reset()
+        b.kld_insert_window(window, count)  # the tree of the new set: every sample, no stop rule
+        leaf, bins = b.kld_counts()
+        M = count
+        lo, hi = (M * self.rank) // W, (M * (self.rank + 1)) // W
+        pose = window[0:3].view(torch.float64)
+        if M <= 8192:
+            b.tail_small(pose[0], pose[1], pose[2], M, lo, hi, leaf, bins)
+        else:
+            b.adopt(pose[0, lo:hi], pose[1, lo:hi], pose[2, lo:hi], hi - lo, M, leaf, bins)
+            b.converged(pose[0, :M], pose[1, :M], M)
+        b.set_rng_state(b.skip(rng, 1))
+        self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
+        self.sample_count = M
+        self.leaf_count, self.bin_count = leaf, bins
+        self.windows_used = 1
+        self.totals = None
+
     # ---- Seam B (multinomial, w_diff == 0)
     def update_resample(self):
         b, W = self.b, self.world
+        if b.resample_model() == 1:  # PF_RESAMPLE_SYSTEMATIC
+            return self._update_resample_systematic()
         b.build_cdf(self.flags)
         if self.totals is not None:
             sums, sums_are_totals = self.totals, True   # slices from the sensor update's totals
@@ -266,11 +353,12 @@ class ShardedFilter:
         self.window_hint = max(1024, ((M + M // 4) + 1023) // 1024 * 1024)
         self.totals = None  # the weights are 1/M now; the old totals no longer describe them
 
-    def restore(self, counts):
+    def restore(self, counts, leaf_count=0):
         """Bench helper: the shards were put back by pf.restore(); reset the bookkeeping."""
         self.counts = list(counts)
         self.sample_count = sum(counts)
         self.totals = None
+        self.leaf_count = leaf_count
 
     def state(self):
         st = self.b.state()

@@ -221,10 +221,11 @@ def main():
         backend = HipShardBackend(e, sc, pf, torch.device("cuda", local_rank))
         sf = ShardedFilter(backend, dist)
         shard_counts = list(sf.counts)
+        shard_leaf = sf.leaf_count  # global leaf count of the initial set (systematic resampler)
 
         def step():
             pf.restore()
-            sf.restore(shard_counts)
+            sf.restore(shard_counts, shard_leaf)
             if odom is not None:
                 sf.update_action(odom, odata)
             sf.update_sensor(data)

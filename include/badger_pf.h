@@ -328,6 +328,19 @@ int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride
  * generation word the host spins on (no D2H copy call, no stream synchronisation), then the replay runs. */
 int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int first_draw_index,
                      int* stop_count_out);
+/* Systematic resampling over shards (particle_filter.cpp:269-354 with w_diff == 0): the targets
+ * start + m / count are formed on the host exactly as the reference's serial chain, every shard resolves the
+ * targets that fall into its slice of the global CDF and writes pose bits + key into its window columns
+ * (zeros elsewhere), as bpf_shard_draw_window_dev does for the multinomial draws.  count =
+ * bpf_pf_resample_limit(leaf count of the current GLOBAL set); rng_state48 = state BEFORE the one drand48. */
+int bpf_pf_resample_limit(bpf_engine* e, int leaf_count, int* count_out);
+int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int count, const void* sums_dev,
+                                    int sums_are_totals, int rank, int world, void* window_dev, int stride,
+                                    void* flags_dev);
+/* insert every key of the window into the engine's histogram tree (no stop rule): the tree of a systematic
+ * resample, or of an initial set (keys as bpf_kld_feed / bpf_kld_feed_dev take them) */
+int bpf_kld_insert(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys);
+int bpf_kld_insert_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys);
 /* the stop rule for a WHOLE candidate stream (draws 0 .. n_keys-1, keys in rows 3..5 of the device window)
  * evaluated on the device (level-synchronous build of the same kd-tree).
  * *handled_out = 0 when a key does not fit the 64-bit packing or the tree is deeper than 256 levels: feed the

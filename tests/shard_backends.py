@@ -78,7 +78,44 @@ class OracleShardBackend:
     def local_sum(self):
         return self._sum
 
+    _resample_model = 0
+
+    def resample_model(self):
+        return self._resample_model
+
+    def resample_limit(self, leaf_count):
+        return self.pfh.resample_limit(leaf_count)
+
+    def systematic_window(self, rng, count, sums, sums_are_totals, rank, world, window, flags):
+        start = lcg_skip(rng, 1) / float(1 << 48)
+        delta = 1.0 / count
+        targets, t = [], start
+        for _ in range(count):
+            targets.append(t)
+            t += delta
+            if t > 1.0:
+                t -= 1.0
+        self._fill_window(targets, 0, sums, sums_are_totals, rank, world, window, flags)
+
+    def kld_insert(self, keys, n):
+        k = keys.numpy()
+        for q in range(n):
+            self.tree.insert_key(k[:, q].astype(np.int32), 1.0)
+
+    def kld_insert_window(self, window, n):
+        self.kld_insert(window[3:6].contiguous(), n)
+
+    def local_pose_keys(self):
+        s = self.samples
+        k = np.stack([np.floor(s[:, 0] / 0.5), np.floor(s[:, 1] / 0.5), np.floor(s[:, 2] / (10 * np.pi / 180))])
+        return torch.from_numpy(k.astype(np.int64))
+
     def draw_window(self, rng, m0, m1, sums, sums_are_totals, rank, world, window, flags):
+        rs = [lcg_skip(rng, 2 * m + 2) / float(1 << 48) for m in range(m0, m1)]
+        self._fill_window(rs, m0, sums, sums_are_totals, rank, world, window, flags)
+
+    def _fill_window(self, rs, m0, sums, sums_are_totals, rank, world, window, flags):
+        m1 = m0 + len(rs)
         s = sums.tolist()
         if sums_are_totals:
             T = 0.0
@@ -94,8 +131,7 @@ class OracleShardBackend:
         n = self.samples.shape[0]
         cell_th = 10 * np.pi / 180
         for m in range(m0, m1):
-            x = lcg_skip(rng, 2 * m + 2)
-            r = x / float(1 << 48)
+            r = rs[m - m0]
             mine = r >= offset and (r < top or rank == world - 1)
             if not mine:
                 continue

@@ -31,7 +31,7 @@ def _scenario(cloud="converged"):
     return orc, Scenario(orc, size=400, n=6000, beams=181, cloud=cloud)
 
 
-def _worker(rank, world, port, out_dir, cloud, device_min):
+def _worker(rank, world, port, out_dir, cloud, device_min, resampler):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -51,6 +51,7 @@ def _worker(rank, world, port, out_dir, cloud, device_min):
     shard.__dict__.update(sc.__dict__)
     shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
     m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    pf.setResampleModel(resampler)
     b = HipShardBackend(e, scn, pf, torch.device("cuda", 0))
     b.kld_device_min = device_min
     sf = ShardedFilter(b, dist, first_window=1024)
@@ -72,14 +73,15 @@ def _worker(rank, world, port, out_dir, cloud, device_min):
     e.close()
 
 
-@pytest.mark.parametrize("cloud,device_min", [("converged", 8192), ("spread", 512)])
-def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min):
+@pytest.mark.parametrize("cloud,device_min,resampler", [("converged", 8192, 0), ("spread", 512, 0),
+                                                        ("converged", 8192, 1)])
+def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min, resampler):
     """converged: early KLD stop inside the first window (host replay).  spread with a low device threshold: no
     stop in the first window, so one window with the whole stream follows and the stop rule runs on the device."""
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), cloud, device_min), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), cloud, device_min, resampler), nprocs=2, join=True)
     recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
 
     import badger_amcl_amd as bpf
@@ -87,6 +89,7 @@ def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min):
     n = sc.samples.shape[0]
     e = bpf.Engine(0)
     m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    pf.setResampleModel(resampler)
     od = bpf.Odom(e)
     od.setModel(*ODOM)
     for cycle in range(2):
@@ -106,6 +109,6 @@ def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min):
         merged = np.concatenate([r0["samples"], r1["samples"]])
         assert np.array_equal(merged[:, :3], cur.samples[:, :3])
         assert np.all(merged[:, 3] == 1.0 / st.sample_count)
-    if cloud == "spread":
+    if cloud == "spread" and resampler == 0:
         assert recs[0][0]["windows"] == 2 and recs[0][0]["M"] > 1024  # first window + the whole-stream window
     e.close()

@@ -32,7 +32,7 @@ def _scenario():
     return orc, Scenario(orc, size=200, n=1200, beams=61, cloud="mixture")
 
 
-def _worker(rank, world, port, out_dir, cloud_split):
+def _worker(rank, world, port, out_dir, cloud_split, resampler):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,6 +45,7 @@ def _worker(rank, world, port, out_dir, cloud_split):
     lo, hi = cloud_split[rank], cloud_split[rank + 1]
     planar = sc.oracle_planar(61, "lf")
     b = OracleShardBackend(orc, sc.omap, planar, sc.samples[lo:hi], 100, n, seed=9)
+    b._resample_model = resampler
     sf = ShardedFilter(b, dist, first_window=256)
     data = (sc.ranges, sc.angles, sc.range_max)
     records = []
@@ -62,17 +63,18 @@ def _worker(rank, world, port, out_dir, cloud_split):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("split", [(0, 600, 1200), (0, 137, 1200)])
-def test_two_shards_equal_one_filter(tmp_path, split):
+@pytest.mark.parametrize("split,resampler", [((0, 600, 1200), 0), ((0, 137, 1200), 0), ((0, 500, 1200), 1)])
+def test_two_shards_equal_one_filter(tmp_path, split, resampler):
     sys.path.insert(0, HERE)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), split), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), split, resampler), nprocs=2, join=True)
     recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
 
     orc, sc = _scenario()
     n = sc.samples.shape[0]
     opf = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0, seed=9)
     opf.set_samples(sc.samples)
+    opf.set_resample_model(resampler)
     p = sc.oracle_planar(61, "lf")
     for cycle in range(2):
         opf.pf.rng = orc.odom_update_action(ODOM[0], ODOM[1], *ODATA, opf.samples[:opf.sample_count], opf.pf.rng)
@@ -96,4 +98,5 @@ def test_two_shards_equal_one_filter(tmp_path, split):
         assert np.all(merged[:, 3] == 1.0 / M)
         # shards are the even, index-ordered split
         assert r0["samples"].shape[0] == M // 2 and r1["samples"].shape[0] == M - M // 2
-    assert recs[0][0]["windows"] >= 2  # first_window=256 forces the multi-window path
+    if resampler == 0:
+        assert recs[0][0]["windows"] >= 2  # first_window=256 forces the multi-window path
