@@ -3048,6 +3048,23 @@ int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* an
   return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
 }
 
+int bpf_shard_score_cloud(bpf_engine* e, const float* points_xyz, int n_points)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  if (e->cloud_max_beams < 2)
+    return BPF_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& s = e->sets[e->cur];
+  e->tile_sums_n = -1;
+  int rc = score_cloud(e, s.dev(), e->sample_count, points_xyz, n_points);
+  if (rc != BPF_OK)
+    return rc;
+  return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
+}
+
 int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr)
 {
   if (!e || !dev_ptr)

@@ -51,6 +51,10 @@ class HipShardBackend:
 
     def score(self, data):
         lib, e = self.e.lib, self.e
+        if hasattr(data, "points_"):  # PointCloudData: the 3-D path
+            e.check(lib.bpf_shard_score_cloud(e.h, data.points_.ctypes.data_as(C.POINTER(C.c_float)),
+                                              data.points_.shape[0]))
+            return
         e.check(lib.bpf_shard_score_planar(e.h, data.ranges_.ctypes.data_as(C.POINTER(C.c_double)),
                                            data.angles_.ctypes.data_as(C.POINTER(C.c_double)), data.range_count_,
                                            data.range_max_))

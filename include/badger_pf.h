@@ -281,6 +281,8 @@ int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_poi
 /* score + recalcWeight on the local shard; the local weight total lands in scalars[0] */
 int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
                            double range_max);
+/* the same for the 3-D path (PointCloudScanner::applyModelToSampleSet on the local shard) */
+int bpf_shard_score_cloud(bpf_engine* e, const float* points_xyz, int n_points);
 /* device address of the engine's scalar block, double[16]: [0] local weight total,
  * [1] w_slow, [2] w_fast, [7] local CDF sum (after bpf_shard_build_cdf) */
 int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr);

@@ -112,3 +112,79 @@ def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min, r
     if cloud == "spread" and resampler == 0:
         assert recs[0][0]["windows"] == 2 and recs[0][0]["M"] > 1024  # first window + the whole-stream window
     e.close()
+
+
+def _cloud_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import badger_amcl_amd as bpf
+    from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+    from oracle import pyoracle as orc
+    from test_gpu_cloud import _setup
+    lut, pts, s, tf_xyz, tf_quat, max_dist = _setup(orc, 3000, 8, 256, seed=6)
+    n = s.shape[0]
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    e = bpf.Engine(0)
+    om = bpf.OctoMap(e, 0.05)
+    om.setDistancesLUT(lut.pose_indices, lut.distance_ratios, lut.min_cells, lut.max_cells, max_dist)
+    sc = bpf.PointCloudScanner(e)
+    sc.init(128, om)
+    sc.setPointCloudModel(0.5, 0.05, 0.1)
+    sc.setMapFactors(0.95, 0.95, 0.3)
+    sc.setPointCloudScannerToFootprintTF(tf_xyz, tf_quat)
+    pf = bpf.ParticleFilter(e, 100, n, 0.0, 0.0, 85.0)
+    pf.srand48(5)
+    pf.initWithSamples(np.ascontiguousarray(s[lo:hi]))
+    sf = ShardedFilter(HipShardBackend(e, sc, pf, torch.device("cuda", 0)), dist, first_window=1024)
+    sf.update_sensor(bpf.PointCloudData(pts))
+    w_after = pf.getCurrentSet().samples.copy()
+    sf.update_resample()
+    st = sf.state()
+    rec = dict(w=w_after, samples=pf.getCurrentSet().samples.copy(), M=st.sample_count, leaf=st.leaf_count,
+               rng=pf.getRngState())
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array([rec], dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    e.close()
+
+
+def test_two_ranks_cloud3d_equal_single_engine(tmp_path):
+    """The 3-D path shards like the planar one: scoring per shard (bpf_shard_score_cloud), then the same
+    exchanges."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_cloud_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True)[0] for r in range(2)]
+    import badger_amcl_amd as bpf
+    from oracle import pyoracle as orc
+    from test_gpu_cloud import _setup
+    lut, pts, s, tf_xyz, tf_quat, max_dist = _setup(orc, 3000, 8, 256, seed=6)
+    e = bpf.Engine(0)
+    om = bpf.OctoMap(e, 0.05)
+    om.setDistancesLUT(lut.pose_indices, lut.distance_ratios, lut.min_cells, lut.max_cells, max_dist)
+    sc = bpf.PointCloudScanner(e)
+    sc.init(128, om)
+    sc.setPointCloudModel(0.5, 0.05, 0.1)
+    sc.setMapFactors(0.95, 0.95, 0.3)
+    sc.setPointCloudScannerToFootprintTF(tf_xyz, tf_quat)
+    pf = bpf.ParticleFilter(e, 100, 3000, 0.0, 0.0, 85.0)
+    pf.srand48(5)
+    pf.initWithSamples(s)
+    sc.updateSensor(pf, bpf.PointCloudData(pts))
+    w_ref = pf.getCurrentSet().samples[:, 3].copy()
+    pf.updateResample()
+    st = pf.getState()
+    w_sh = np.concatenate([recs[0]["w"][:, 3], recs[1]["w"][:, 3]])
+    assert np.allclose(w_sh, w_ref, rtol=1e-12, atol=0)
+    for r in recs:
+        assert r["M"] == st.sample_count and r["leaf"] == st.leaf_count and r["rng"] == pf.getRngState()
+    merged = np.concatenate([recs[0]["samples"], recs[1]["samples"]])
+    assert np.array_equal(merged[:, :3], pf.getCurrentSet().samples[:, :3])
+    e.close()
