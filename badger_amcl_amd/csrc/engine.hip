@@ -1301,7 +1301,6 @@ int resample_systematic(bpf_engine* e)
   e->rng = lcg_skip_host(e->rng, 1, e->jump);
   const double start = std::ldexp((double)e->rng, -48);
   const double delta = 1.0 / count;
-  HIPCHK(e, e->d_targets.reserve((size_t)e->max_samples));
   HIPCHK(e, e->d_keys.reserve((size_t)e->max_samples * 3));
   HIPCHK(e, e->d_src_index.reserve((size_t)e->max_samples));
   HIPCHK(e, e->h_keys.reserve((size_t)e->max_samples * 3));
@@ -1309,7 +1308,6 @@ int resample_systematic(bpf_engine* e)
   A.src = a.dev();
   A.n_src = n;
   A.cdf = e->d_cdf.p;
-  A.targets = e->d_targets.p;
   A.dst = b.dev();
   A.count = count;
   A.keys = e->d_keys.p;

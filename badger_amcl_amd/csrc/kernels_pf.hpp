@@ -757,23 +757,6 @@ __global__ void k_adopt(const double* __restrict__ x, const double* __restrict__
   dst.w[i] = weight;
 }
 
-// Systematic resampler targets (particle_filter.cpp:326-341): target_0 = start, then
-// target += delta; if (target > 1) target -= 1 -- a serial floating-point chain, kept serial
-// (one lane) so every target carries the reference's rounding.
-__global__ void k_systematic_targets(double start, double delta, int count, double* __restrict__ targets)
-{
-  if (blockIdx.x != 0 || threadIdx.x != 0)
-    return;
-  double t = start;
-  for (int i = 0; i < count; ++i)
-  {
-    targets[i] = t;
-    t += delta;
-    if (t > 1.0)
-      t -= 1.0;
-  }
-}
-
 struct SystematicArgs
 {
   ParticlesDev src;
@@ -854,13 +837,6 @@ __global__ void k_window_keys_to_aos(const long long* __restrict__ window, int s
     keys[3 * (size_t)q + 1] = (int)window[(size_t)4 * stride + q];
     keys[3 * (size_t)q + 2] = (int)window[(size_t)5 * stride + q];
   }
-}
-
-__global__ void k_pose_keys(ParticlesDev p, int n, int* __restrict__ keys)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    pose_key(p.x[i], p.y[i], p.th[i], &keys[3 * i]);
 }
 
 // ------------------------------------------------------------------ updateConverged

@@ -352,3 +352,30 @@ def test_full_size_properties(engine, orc):
     # and the KLD stop rule holds exactly at M and at no earlier draw
     opf = orc.ParticleFilter(100, n)
     assert M > opf.resample_limit(st1.leaf_count) or M == n
+
+
+def test_lds_window_scoring_path_matches_oracle(engine, orc):
+    """BPF_OPT_WINDOW_PATH (opt-in; a measured negative result on wide clouds): the LDS-window
+    kernels must give the same weights as the oracle when the device-side switch takes them."""
+    import badger_amcl_amd.pf as hpf
+    from badger_amcl_amd import synth
+    # 1081 beams: a chunk of 64 consecutive beams is a 16-degree arc; range_max 8 m keeps the arcs short
+    sc_ = Scenario(orc, size=400, n=16384, beams=1081, cloud="converged", frac_nan=0.0, range_max=8.0)
+    # a tight cloud, so that every chunk's 3-sigma footprint fits a window and the device-side switch takes them
+    sc_.samples = synth.converged_cloud(16384, sc_.pose, seed=77, sigma=(0.05, 0.05, 0.01))
+    sc_.samples[:, 3] *= np.random.default_rng(78).uniform(0.5, 1.5, 16384)
+    engine.set_option(hpf.OPT_WINDOW_PATH, 1)
+    try:
+        m, sc, pf, data = sc_.gpu_objects(engine, 1081, "lf")
+        sc.updateSensor(pf, data)
+        got = pf.getCurrentSet().samples
+        plan = engine.window_plan()
+    finally:
+        engine.set_option(hpf.OPT_WINDOW_PATH, 0)
+    opf = orc.ParticleFilter(100, 16384, 0.0, 0.0, 85.0)
+    opf.set_samples(sc_.samples, leaf_count=1)
+    p = sc_.oracle_planar(1081, "lf")
+    opf.update_sensor(lambda s, conv: sc_.oracle_apply(p, s, conv))
+    bad = rel_err(got[:, 3], opf.samples[:16384, 3]) > W_TOL
+    assert bad.sum() <= _knife_edge_budget(16384 * 1081)
+    assert plan["chunks_total"] == 17 and plan["used_window"], plan  # the device-side switch took the windows
