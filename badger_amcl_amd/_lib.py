@@ -63,6 +63,7 @@ SIGNATURES = {
     "bpf_pf_restore": (C.c_int, [_vp]),
     "bpf_pf_fill_weights": (C.c_int, [_vp, C.c_double]),
     "bpf_pf_update_sensor_planar": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double]),
+    "bpf_pf_set_random_pose_generator": (C.c_int, [_vp, C.c_int]),
     "bpf_pf_update_resample": (C.c_int, [_vp]),
     "bpf_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "bpf_get_cells_walked": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),

@@ -19,6 +19,7 @@
 #include "kernels_cloud.hpp"
 #include "kernels_motion.hpp"
 #include "kernels_kld.hpp"
+#include "kernels_recovery.hpp"
 #include "kernels_pf.hpp"
 #include "kernels_score.hpp"
 #include "kernels_window.hpp"
@@ -239,6 +240,17 @@ struct bpf_engine
   SampleSet snap;
   int snap_count = 0, snap_leaf = 0, snap_bins = 0;
 
+  // ---- w_diff > 0: random free-space poses (Node::randomFreeSpacePose) and the draw chain
+  int random_pose_mode = BPF_RANDOM_POSE_NONE;
+  std::vector<float> h_lut_f32;     // the LUT as floats (free-space test: distance > non_free_space_radius)
+  DevBuf<int2> d_free_ij;
+  int n_free = 0;
+  int free_map_version = -1;
+  double free_radius = -1.0;
+  DevBuf<uint64_t> d_chain_bits;
+  DevBuf<int> d_chain_cnt, d_chain_exit, d_chain_entry, d_chain_base, d_chain;
+  PinnedBuf<int> h_chain_word;
+
   // ---- KLD stop rule on the device (long draw streams)
   int kld_device_min = 8192;  // draws left after the first window from which the device tree takes over
   bool kld_device_used = false;
@@ -410,6 +422,7 @@ int encode_lut(bpf_engine* e, const float* lut)
   HIPCHK(e, e->d_lut_f32.reserve(ncell));
   HIPCHK(e, hipMemcpy(e->d_lut_f32.p, lut, ncell * sizeof(float), hipMemcpyHostToDevice));
   e->h_levels = levels;
+  e->h_lut_f32.assign(lut, lut + ncell);
   e->map.lut_tiles = e->d_lut_tiles.p;
   e->map.levels = e->d_levels.p;
   e->map.n_levels = (int)levels.size();
@@ -1036,6 +1049,80 @@ int launch_converged(bpf_engine* e)
   return BPF_OK;
 }
 
+// Node2D::updateFreeSpaceIndices (node_2d.cpp:317-337) for the current map and non_free_space_radius, cached
+int ensure_free_space(bpf_engine* e, FreeSpaceDev* out)
+{
+  if (e->random_pose_mode != BPF_RANDOM_POSE_FREE_SPACE_2D)
+    return e->fail(BPF_ERR_UNSUPPORTED,
+                   "w_diff > 0: random pose injection needs a pose generator (bpf_pf_set_random_pose_generator); "
+                   "the node's random_pose_fn_ callback (particle_filter.cpp:385-388) cannot be called from here");
+  if (!e->have_map || !e->have_lut)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "random free-space poses need the 2-D map and its distance LUT");
+  const double radius = e->pm.non_free_radius;
+  if (e->free_map_version != e->map_version || e->free_radius != radius)
+  {
+    const int sx = e->map.size_x, sy = e->map.size_y;
+    std::vector<int2> ij;
+    ij.reserve((size_t)sx * sy / 2);
+    for (int i = 0; i < sx; ++i)
+      for (int j = 0; j < sy; ++j)
+      {
+        const size_t idx = i + (size_t)j * sx;
+        if (e->h_cells8[idx] == -1 && (double)e->h_lut_f32[idx] > radius)
+          ij.push_back(make_int2(i, j));
+      }
+    e->n_free = (int)ij.size();
+    HIPCHK(e, e->d_free_ij.reserve(std::max<size_t>(ij.size(), 1)));
+    if (!ij.empty())
+      HIPCHK(e, hipMemcpy(e->d_free_ij.p, ij.data(), ij.size() * sizeof(int2), hipMemcpyHostToDevice));
+    e->free_map_version = e->map_version;
+    e->free_radius = radius;
+  }
+  if (e->n_free <= 0)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "the map has no free cell to draw random poses from");
+  out->ij = e->d_free_ij.p;
+  out->n = e->n_free;
+  out->size_x = e->map.size_x;
+  out->size_y = e->map.size_y;
+  out->origin_x = e->map.origin_x;
+  out->origin_y = e->map.origin_y;
+  out->resolution = e->map.resolution;
+  return BPF_OK;
+}
+
+// Where every candidate draw 0 .. max_draws finds its stream elements when w_diff > 0 (kernels_recovery.hpp)
+int build_draw_chain(bpf_engine* e, double w_diff, int max_draws)
+{
+  const long long positions = 3ll * ((long long)max_draws + 1) + 3;
+  if (positions >= 0x7fffffffll)
+    return e->fail(BPF_ERR_CAPACITY, "draw chain would pass 31-bit stream positions");
+  const int n_seg = (int)((positions + kChainSeg - 1) / kChainSeg);
+  HIPCHK(e, e->d_chain_bits.reserve((size_t)2 * n_seg));
+  HIPCHK(e, e->d_chain_cnt.reserve((size_t)3 * n_seg));
+  HIPCHK(e, e->d_chain_exit.reserve((size_t)3 * n_seg));
+  HIPCHK(e, e->d_chain_entry.reserve((size_t)n_seg));
+  HIPCHK(e, e->d_chain_base.reserve((size_t)n_seg));
+  HIPCHK(e, e->d_chain.reserve((size_t)max_draws + 1));
+  ChainArgs C{};
+  C.rng_state = e->rng;
+  C.w_diff = w_diff;
+  C.n_seg = n_seg;
+  C.max_draws = max_draws;
+  C.seg_bits = e->d_chain_bits.p;
+  C.seg_cnt = e->d_chain_cnt.p;
+  C.seg_exit = e->d_chain_exit.p;
+  C.seg_entry = e->d_chain_entry.p;
+  C.seg_base = e->d_chain_base.p;
+  C.chain = e->d_chain.p;
+  C.jump = e->jump;
+  ProfScope ps(e, BPF_K_DRAW);
+  hipLaunchKernelGGL(k_chain_segments, dim3(blocks_for(n_seg, 256)), dim3(256), 0, e->stream, C);
+  hipLaunchKernelGGL(k_chain_scan, dim3(1), dim3(1024), 0, e->stream, C);
+  hipLaunchKernelGGL(k_chain_emit, dim3(blocks_for(n_seg, 256)), dim3(256), 0, e->stream, C);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
 // The KLD stop rule for the whole candidate stream [0, maxs) on the device (kernels_kld.hpp), keys in
 // e->d_keys (AoS): grows the histogram tree level by level and scans the leaf count.
 // Returns BPF_OK with *stop_out = stop count (or -1: no stop), *leaf_out / *bins_out at the final count;
@@ -1174,12 +1261,26 @@ bool wait_generation(bpf_engine* e, unsigned generation)
   }
 }
 
-int resample_multinomial(bpf_engine* e)
+int resample_multinomial(bpf_engine* e, double w_diff)
 {
   SampleSet& a = e->sets[e->cur];
   SampleSet& b = e->sets[e->cur ^ 1];
   const int n = e->sample_count;
   const int maxs = e->max_samples;
+  FreeSpaceDev free_space{};
+  const int* chain = nullptr;
+  if (w_diff > 0.0)
+  {
+    // :383-388: every draw first tests a uniform against w_diff; where each draw finds its stream elements is
+    // resolved up front for all candidate draws
+    int rcf = ensure_free_space(e, &free_space);
+    if (rcf != BPF_OK)
+      return rcf;
+    rcf = build_draw_chain(e, w_diff, maxs);
+    if (rcf != BPF_OK)
+      return rcf;
+    chain = e->d_chain.p;
+  }
   HIPCHK(e, e->d_keys.reserve((size_t)maxs * 3));
   HIPCHK(e, e->d_src_index.reserve((size_t)maxs));
   HIPCHK(e, e->h_keys.reserve((size_t)maxs * 3));
@@ -1210,6 +1311,8 @@ int resample_multinomial(bpf_engine* e)
     A.src_index = e->d_src_index.p;
     A.miss_flag = e->d_flags.p;
     A.sharded = 0;
+    A.chain = chain;
+    A.free_space = free_space;
     // long stream ahead: either the first window found no stop, or the previous cycle ran to the end
     const bool long_stream = (m0 > 0 || e->window_hint >= maxs) && maxs - m0 >= e->kld_device_min;
     if (long_stream && !device_declined)
@@ -1286,21 +1389,49 @@ int resample_multinomial(bpf_engine* e)
   }
   const int M = (stop > 0) ? stop : maxs;
   // the window that found the stop also inserted nothing past it: hist is exactly set b's tree
-  e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)M, e->jump);
+  if (chain != nullptr)
+  {
+    // the stream was consumed up to the element before draw M's test
+    HIPCHK(e, e->h_chain_word.reserve(1));
+    HIPCHK(e, hipMemcpyAsync(e->h_chain_word.p, chain + M, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const unsigned next_test = (unsigned)e->h_chain_word.p[0] & 0x7fffffffu;
+    e->rng = lcg_skip_host(e->rng, (uint64_t)next_test - 1ull, e->jump);
+  }
+  else
+    e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)M, e->jump);
   e->window_hint = std::max(1024, ((M + M / 4) + 1023) / 1024 * 1024);
   e->sample_count = M;
   return BPF_OK;
 }
 
-int resample_systematic(bpf_engine* e)
+int resample_systematic(bpf_engine* e, double w_diff)
 {
   SampleSet& a = e->sets[e->cur];
   SampleSet& b = e->sets[e->cur ^ 1];
   const int n = e->sample_count;
-  const int count = resample_limit(e->leaf_count, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+  int count = resample_limit(e->leaf_count, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+  FreeSpaceDev free_space{};
+  int num_random = 0;
+  if (w_diff > 0.0)
+  {
+    // particle_filter.cpp:295-306: room for random poses on top of the systematic ones
+    count *= (1.0 + w_diff);
+    if (count > e->max_samples)
+      count = e->max_samples;
+    num_random = (int)(w_diff * count);
+    if (num_random > 0)
+    {
+      int rcf = ensure_free_space(e, &free_space);
+      if (rcf != BPF_OK)
+        return rcf;
+    }
+  }
+  const int num_systematic = count - num_random;
+  const uint64_t rng_before = e->rng;
   e->rng = lcg_skip_host(e->rng, 1, e->jump);
   const double start = std::ldexp((double)e->rng, -48);
-  const double delta = 1.0 / count;
+  const double delta = 1.0 / num_systematic;
   HIPCHK(e, e->d_keys.reserve((size_t)e->max_samples * 3));
   HIPCHK(e, e->d_src_index.reserve((size_t)e->max_samples));
   HIPCHK(e, e->h_keys.reserve((size_t)e->max_samples * 3));
@@ -1310,6 +1441,10 @@ int resample_systematic(bpf_engine* e)
   A.cdf = e->d_cdf.p;
   A.dst = b.dev();
   A.count = count;
+  A.n_random = num_random;
+  A.rng_state = rng_before;
+  A.jump = e->jump;
+  A.free_space = free_space;
   A.keys = e->d_keys.p;
   A.src_index = e->d_src_index.p;
   A.miss_flag = e->d_flags.p;
@@ -1320,7 +1455,7 @@ int resample_systematic(bpf_engine* e)
   {
     double t = start;
     double* out = e->h_targets.p;
-    for (int i = 0; i < count; ++i)
+    for (int i = 0; i < num_systematic; ++i)
     {
       out[i] = t;
       t += delta;
@@ -1368,6 +1503,8 @@ int resample_systematic(bpf_engine* e)
     if (e->seen.first_time(k0, k1, k2))
       e->hist.insert(k0, k1, k2);
   }
+  // :316-324: the random poses took two uniforms each, right after the systematic start
+  e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)num_random, e->jump);
   e->resample_windows = 1;
   e->sample_count = count;
   return BPF_OK;
@@ -1752,6 +1889,7 @@ int bpf_pf_create(bpf_engine* e, int min_samples, int max_samples, double alpha_
   e->pop_z = 3;
   e->dist_threshold = 0.5;
   e->resample_model = BPF_RESAMPLE_MULTINOMIAL;
+  e->random_pose_mode = BPF_RANDOM_POSE_NONE;  // the constructor's random_pose_fn: none until one is set
   for (int k = 0; k < 2; ++k)
     HIPCHK(e, e->sets[k].reserve((size_t)max_samples));
   // ctor state (particle_filter.cpp:62-89): max_samples particles at the origin, weight 1/max
@@ -1987,6 +2125,16 @@ int bpf_pf_update_sensor_planar(bpf_engine* e, const double* ranges, const doubl
   return BPF_OK;
 }
 
+int bpf_pf_set_random_pose_generator(bpf_engine* e, int mode)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (mode != BPF_RANDOM_POSE_NONE && mode != BPF_RANDOM_POSE_FREE_SPACE_2D)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown random pose generator");
+  e->random_pose_mode = mode;
+  return BPF_OK;
+}
+
 int bpf_pf_update_resample(bpf_engine* e)
 {
   if (!e)
@@ -2007,10 +2155,6 @@ int bpf_pf_update_resample(bpf_engine* e)
     w_diff = 1.0 - wf / ws;
     if (!(w_diff >= 0.0))
       w_diff = 0.0;
-    if (w_diff > 0.0)
-      return e->fail(BPF_ERR_UNSUPPORTED,
-                     "w_diff > 0: random pose injection needs the node's random_pose_fn_ callback "
-                     "(particle_filter.cpp:385-388); not available on the device path");
   }
   e->w_diff_last = w_diff;
   SampleSet& a = e->sets[e->cur];
@@ -2018,9 +2162,12 @@ int bpf_pf_update_resample(bpf_engine* e)
   if (rc != BPF_OK)
     return rc;
   e->kld_device_used = false;
-  rc = (e->resample_model == BPF_RESAMPLE_SYSTEMATIC) ? resample_systematic(e) : resample_multinomial(e);
+  rc = (e->resample_model == BPF_RESAMPLE_SYSTEMATIC) ? resample_systematic(e, w_diff)
+                                                      : resample_multinomial(e, w_diff);
   if (rc != BPF_OK)
     return rc;
+  if (w_diff > 0.0)  // "Reset averages, to avoid spiraling off into complete randomness" (particle_filter.cpp:453-455)
+    HIPCHK(e, hipMemsetAsync(&e->d_scalars.p->v[1], 0, 2 * sizeof(double), e->stream));
   const int M = e->sample_count;
   SampleSet& b = e->sets[e->cur ^ 1];
   e->tile_sums_n = -1;

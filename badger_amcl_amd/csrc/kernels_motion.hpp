@@ -44,11 +44,6 @@ struct MotionRngArgs
   LcgJump jump;
 };
 
-__device__ __forceinline__ uint64_t lcg_next(uint64_t x)
-{
-  return (0x5DEECE66Dull * x + 0xBull) & ((1ull << 48) - 1);
-}
-
 // Walks the kMotionRun attempts of one thread.  f(k, accepted, x2, w, raw_index_of_second_uniform).
 template <class F>
 __device__ __forceinline__ void motion_attempts(const MotionRngArgs& A, long long t0, F&& f)

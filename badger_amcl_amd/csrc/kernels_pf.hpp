@@ -532,6 +532,32 @@ __device__ __forceinline__ void pose_key(double x, double y, double th, int* key
   key[2] = (int)floor(th / cell_th);
 }
 
+__device__ __forceinline__ uint64_t lcg_next(uint64_t x)
+{
+  return (0x5DEECE66Dull * x + 0xBull) & ((1ull << 48) - 1);
+}
+
+// Node::randomFreeSpacePose (node.cpp:823-845) from two uniforms, with OccupancyMap::convertMapToWorld
+// (occupancy_map.cpp:75-88); free_ij = Node2D::updateFreeSpaceIndices (node_2d.cpp:317-337)
+struct FreeSpaceDev
+{
+  const int2* ij;
+  int n;
+  int size_x, size_y;
+  double origin_x, origin_y, resolution;
+};
+
+__device__ __forceinline__ void random_free_space_pose(const FreeSpaceDev& F, double r1, double r2, double* x,
+                                                       double* y, double* th)
+{
+#pragma clang fp contract(off)
+  const unsigned idx = (unsigned)(r1 * F.n);
+  const int2 c = F.ij[idx];
+  *x = F.origin_x + (c.x - F.size_x / 2) * F.resolution;
+  *y = F.origin_y + (c.y - F.size_y / 2) * F.resolution;
+  *th = r2 * 2 * 3.14159265358979323846 - 3.14159265358979323846;
+}
+
 struct DrawArgs
 {
   ParticlesDev src;      // set a
@@ -556,18 +582,55 @@ struct DrawArgs
   unsigned* done_counter;       // device word, 0 between launches
   volatile unsigned* host_done; // pinned host word
   unsigned generation;
+  // w_diff > 0 (kernels_recovery.hpp): position of draw m's test element in the stream, bit 31 = the draw is
+  // a random free-space pose (nullptr: w_diff == 0, draw m tests element 2m+1 and takes r from 2m+2)
+  const int* chain;
+  FreeSpaceDev free_space;
 };
 
-// Multinomial resampler body for w_diff == 0 (particle_filter.cpp:381-414): draw m consumes
-// stream elements 2m+1 (compared with w_diff) and 2m+2 (r).
+// Multinomial resampler body (particle_filter.cpp:381-414): with w_diff == 0 draw m consumes stream elements
+// 2m+1 (compared with w_diff) and 2m+2 (r); with w_diff > 0 the chain says where its elements are.
 __device__ __forceinline__ void draw_select_body(const DrawArgs& A)
 {
   const int m = A.m0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= A.m1)
     return;
-  const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
-  double r = ldexp((double)xs, -48);
   const int o = m - A.m0;
+  uint64_t xs;
+  if (A.chain != nullptr)
+  {
+    const int c = A.chain[m];
+    xs = lcg_skip(A.rng_state, (uint64_t)(c & 0x7fffffff) + 1ull, A.jump);
+    if (c < 0)
+    {
+      // :385-388: random_pose_fn_() = Node::randomFreeSpacePose, the next two stream elements
+      const double r1 = ldexp((double)xs, -48), r2 = ldexp((double)lcg_next(xs), -48);
+      double x, y, th;
+      random_free_space_pose(A.free_space, r1, r2, &x, &y, &th);
+      if (A.dst.x != nullptr)
+      {
+        A.dst.x[m] = x;
+        A.dst.y[m] = y;
+        A.dst.th[m] = th;
+      }
+      A.src_index[o] = -1;
+      int key[3];
+      pose_key(x, y, th, key);
+      A.keys[3 * o] = key[0];
+      A.keys[3 * o + 1] = key[1];
+      A.keys[3 * o + 2] = key[2];
+      if (A.host_keys != nullptr)
+      {
+        A.host_keys[o] = key[0];
+        A.host_keys[A.host_stride + o] = key[1];
+        A.host_keys[2 * A.host_stride + o] = key[2];
+      }
+      return;
+    }
+  }
+  else
+    xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
+  double r = ldexp((double)xs, -48);
   int i;
   if (A.sharded)
   {
@@ -774,6 +837,12 @@ struct SystematicArgs
   unsigned* done_counter;
   volatile unsigned* host_done;
   unsigned generation;
+  // w_diff > 0 (particle_filter.cpp:295-324): the first n_random samples are random free-space poses from stream
+  // elements 2i+2, 2i+3 (element 1 is the systematic start); targets[] then belongs to samples n_random ..
+  int n_random;
+  uint64_t rng_state;
+  LcgJump jump;
+  FreeSpaceDev free_space;
 };
 
 // The reference walks the CDF cyclically from the previous hit (particle_filter.cpp:329-336);
@@ -783,13 +852,25 @@ __global__ void k_systematic_select(const SystematicArgs A)
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m < A.count)
   {
-    int i = cdf_find(A.cdf, A.n_src, A.targets[m]);
-    if (i >= A.n_src)
+    double x, y, th;
+    int i = -1;
+    if (m < A.n_random)
     {
-      atomicExch(A.miss_flag, 1);  // the reference never leaves its while loop here
-      i = A.n_src - 1;
+      const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
+      random_free_space_pose(A.free_space, ldexp((double)xs, -48), ldexp((double)lcg_next(xs), -48), &x, &y, &th);
     }
-    const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
+    else
+    {
+      i = cdf_find(A.cdf, A.n_src, A.targets[m - A.n_random]);
+      if (i >= A.n_src)
+      {
+        atomicExch(A.miss_flag, 1);  // the reference never leaves its while loop here
+        i = A.n_src - 1;
+      }
+      x = A.src.x[i];
+      y = A.src.y[i];
+      th = A.src.th[i];
+    }
     A.dst.x[m] = x;
     A.dst.y[m] = y;
     A.dst.th[m] = th;

@@ -20,6 +20,7 @@ from . import _lib
 
 MODEL_BEAM, MODEL_LIKELIHOOD_FIELD, MODEL_LIKELIHOOD_FIELD_PROB, MODEL_LIKELIHOOD_FIELD_GOMPERTZ = 0, 1, 2, 3
 PF_RESAMPLE_MULTINOMIAL, PF_RESAMPLE_SYSTEMATIC = 0, 1
+RANDOM_POSE_NONE, RANDOM_POSE_FREE_SPACE_2D = 0, 1
 OPT_CDF_SERIAL, OPT_COUNT_CELLS, OPT_WINDOW_PATH, OPT_KLD_DEVICE_MIN = 0, 1, 2, 3
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
@@ -215,6 +216,10 @@ class ParticleFilter:
 
     def _setResampleModel(self, model):
         self.e.check(self.e.lib.bpf_pf_set_resample_model(self.e.h, model))
+
+    def setRandomPoseGenerator(self, mode):
+        """random_pose_fn of the reference's constructor: RANDOM_POSE_FREE_SPACE_2D = Node::randomFreeSpacePose."""
+        self.e.check(self.e.lib.bpf_pf_set_random_pose_generator(self.e.h, int(mode)))
 
     def setPopulationSizeParameters(self, pop_err, pop_z):
         self.e.check(self.e.lib.bpf_pf_set_population_size_parameters(self.e.h, pop_err, pop_z))

@@ -144,6 +144,11 @@ public:
                             global_localization_convergence_threshold));
   }
   void setResampleModel(PFResampleModelType m) { e_->check(bpf_pf_set_resample_model(e_->get(), m)); }
+  // random_pose_fn of the reference's constructor: true = Node::randomFreeSpacePose on the device (badger_pf.h)
+  void setRandomFreeSpacePoseGenerator(bool on)
+  {
+    e_->check(bpf_pf_set_random_pose_generator(e_->get(), on ? BPF_RANDOM_POSE_FREE_SPACE_2D : BPF_RANDOM_POSE_NONE));
+  }
   void setPopulationSizeParameters(double pop_err, double pop_z)
   {
     e_->check(bpf_pf_set_population_size_parameters(e_->get(), pop_err, pop_z));

@@ -155,6 +155,20 @@ int bpf_pf_fill_weights(bpf_engine* e, double weight);
  * (planar_scanner.cpp:125-137, particle_filter.cpp:223-267).  Asynchronous. */
 int bpf_pf_update_sensor_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
                                 double range_max);
+/* random_pose_fn_ of the ParticleFilter constructor (particle_filter.cpp:40-47), used by both resamplers when
+ * w_diff = max(0, 1 - w_fast / w_slow) > 0 (augmented-MCL recovery, :295-324 and :383-388).  The node passes
+ * Node::uniformPoseGenerator; with its score check disabled (uniform_pose_starting_weight_threshold = 0, the
+ * node's default, node.cpp:124,847-868) that is Node::randomFreeSpacePose (node.cpp:823-845): two drand48 draws,
+ * a uniformly chosen cell of Node2D::updateFreeSpaceIndices (node_2d.cpp:317-337: FREE and further than
+ * non_free_space_radius from an obstacle) and a uniform heading.  BPF_RANDOM_POSE_FREE_SPACE_2D evaluates exactly
+ * that on the device from the engine's own 2-D map, drawing from the filter's drand48 stream in the reference's
+ * order; with BPF_RANDOM_POSE_NONE (default) a resample that needs random poses returns BPF_ERR_UNSUPPORTED. */
+enum
+{
+  BPF_RANDOM_POSE_NONE = 0,
+  BPF_RANDOM_POSE_FREE_SPACE_2D = 1
+};
+int bpf_pf_set_random_pose_generator(bpf_engine* e, int mode);
 /* Seam B: ParticleFilter::updateResample (particle_filter.cpp:423-471). */
 int bpf_pf_update_resample(bpf_engine* e);
 

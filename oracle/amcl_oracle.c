@@ -1080,6 +1080,34 @@ static int cdf_find(const double* c, int n, double r)
   return lo;
 }
 
+/* Node2D::updateFreeSpaceIndices, node_2d.cpp:317-337 */
+int orc_free_space_indices(const orc_map2d* m, double non_free_space_radius, int* ij_out, int capacity)
+{
+  int n = 0;
+  for (int i = 0; i < m->size_x; i++)
+    for (int j = 0; j < m->size_y; j++)
+      if (m->cells[cell_index(m, i, j)] == -1 && (double)orc_map2d_distance(m, i, j) > non_free_space_radius)
+      {
+        if (ij_out && n < capacity)
+        {
+          ij_out[2 * n] = i;
+          ij_out[2 * n + 1] = j;
+        }
+        n++;
+      }
+  return n;
+}
+
+/* Node::randomFreeSpacePose, node.cpp:823-845 (with OccupancyMap::convertMapToWorld, occupancy_map.cpp:75-88) */
+void orc_random_free_space_pose(const orc_free_space* fs, uint64_t* rng, double pose[3])
+{
+  const unsigned int rand_index = (unsigned int)(orc_drand48(rng) * fs->n);
+  const int i = fs->ij[2 * rand_index], j = fs->ij[2 * rand_index + 1];
+  pose[0] = fs->origin_x + (i - fs->size_x / 2) * fs->resolution;
+  pose[1] = fs->origin_y + (j - fs->size_y / 2) * fs->resolution;
+  pose[2] = orc_drand48(rng) * 2 * M_PI - M_PI;
+}
+
 /* particle_filter.cpp:356-420 */
 static double resample_multinomial(orc_pf* pf, const double* a, int n_a, double w_diff, double* b, int* idx,
                                    orc_kdtree* tree, int* m_out, int* status)
@@ -1095,22 +1123,32 @@ static double resample_multinomial(orc_pf* pf, const double* a, int n_a, double 
     double* out = &b[4 * m];
     if (orc_drand48(&pf->rng) < w_diff)
     {
-      *status = 2; /* random_pose_fn_ is a node callback; not available to the oracle */
-      break;
+      if (!pf->random_source || pf->random_source->n <= 0)
+      {
+        *status = 2; /* random_pose_fn_ is a node callback; no generator was handed to the oracle */
+        break;
+      }
+      orc_random_free_space_pose(pf->random_source, &pf->rng, out); /* :385-388 */
+      out[3] = 1.0;
+      if (idx)
+        idx[m] = -1;
     }
-    const double r = orc_drand48(&pf->rng);
-    int i = cdf_find(c, n_a, r);
-    if (i >= n_a)
+    else
     {
-      *status = 1; /* ROS_ASSERT(i < sample_count) */
-      i = n_a - 1;
+      const double r = orc_drand48(&pf->rng);
+      int i = cdf_find(c, n_a, r);
+      if (i >= n_a)
+      {
+        *status = 1; /* ROS_ASSERT(i < sample_count) */
+        i = n_a - 1;
+      }
+      out[0] = a[4 * i];
+      out[1] = a[4 * i + 1];
+      out[2] = a[4 * i + 2];
+      out[3] = 1.0;
+      if (idx)
+        idx[m] = i;
     }
-    out[0] = a[4 * i];
-    out[1] = a[4 * i + 1];
-    out[2] = a[4 * i + 2];
-    out[3] = 1.0;
-    if (idx)
-      idx[m] = i;
     m++;
     total += 1.0;
     orc_kdtree_insert(tree, out, 1.0);
@@ -1149,12 +1187,22 @@ static double resample_systematic(orc_pf* pf, const double* a, int n_a, int prev
   if (ci >= n_a)
     ci = 0; /* the reference would read c[n+1] once and then wrap to 0 */
   int i = 0;
-  if (num_random > 0)
+  if (num_random > 0 && (!pf->random_source || pf->random_source->n <= 0))
   {
     *status = 2;
     free(c);
     *m_out = 0;
     return 0;
+  }
+  for (; i < num_random; ++i) /* :316-324 */
+  {
+    double* out = &b[4 * i];
+    orc_random_free_space_pose(pf->random_source, &pf->rng, out);
+    out[3] = 1.0;
+    if (idx)
+      idx[i] = -1;
+    total += 1.0;
+    orc_kdtree_insert(tree, out, 1.0);
   }
   double target = start;
   for (; i < new_count; ++i)

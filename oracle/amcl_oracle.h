@@ -126,7 +126,25 @@ typedef struct
   int resample_model;
   uint64_t rng;                 /* the process-global drand48 state */
   int converged;
+  /* random_pose_fn_ (particle_filter.cpp:40-47): NULL = not available (w_diff > 0 reports status 2); otherwise
+   * Node::uniformPoseGenerator with its score check disabled (uniform_pose_starting_weight_threshold = 0, the
+   * node's default, node.cpp:124) = Node::randomFreeSpacePose over this free-cell list (node.cpp:823-845) */
+  const struct orc_free_space* random_source;
 } orc_pf;
+
+/* Node2D::updateFreeSpaceIndices (node_2d.cpp:317-337): FREE cells further than non_free_space_radius from an
+ * obstacle, i outer / j inner, plus what convertMapToWorld needs */
+typedef struct orc_free_space
+{
+  int n;
+  const int* ij; /* [n][2] */
+  int size_x, size_y;
+  double origin_x, origin_y, resolution;
+} orc_free_space;
+/* returns the number of free cells; ij_out (capacity pairs) may be NULL to count only */
+int orc_free_space_indices(const orc_map2d* m, double non_free_space_radius, int* ij_out, int capacity);
+/* Node::randomFreeSpacePose: two drand48 draws */
+void orc_random_free_space_pose(const orc_free_space* fs, uint64_t* rng, double pose[3]);
 
 void orc_pf_init(orc_pf* pf, int min_samples, int max_samples, double alpha_slow, double alpha_fast,
                  double convergence_threshold);

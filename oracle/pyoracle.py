@@ -54,7 +54,13 @@ class PF(C.Structure):
                 ("alpha_slow", C.c_double), ("alpha_fast", C.c_double),
                 ("w_slow", C.c_double), ("w_fast", C.c_double),
                 ("dist_threshold", C.c_double), ("convergence_threshold", C.c_double),
-                ("resample_model", C.c_int), ("rng", C.c_uint64), ("converged", C.c_int)]
+                ("resample_model", C.c_int), ("rng", C.c_uint64), ("converged", C.c_int),
+                ("random_source", C.c_void_p)]
+
+
+class FreeSpace(C.Structure):
+    _fields_ = [("n", C.c_int), ("ij", C.POINTER(C.c_int)), ("size_x", C.c_int), ("size_y", C.c_int),
+                ("origin_x", C.c_double), ("origin_y", C.c_double), ("resolution", C.c_double)]
 
 
 class ResampleOut(C.Structure):
@@ -125,6 +131,9 @@ def lib():
     L.orc_pf_resample_limit.argtypes = [C.POINTER(PF), C.c_int]
     L.orc_pf_update_resample.argtypes = [C.POINTER(PF), dp, C.c_int, C.c_int, dp, ip, C.POINTER(ResampleOut)]
     L.orc_pf_update_converged.argtypes = [C.POINTER(PF), dp, C.c_int, C.POINTER(C.c_float)]
+    L.orc_free_space_indices.argtypes = [C.POINTER(Map2D), C.c_double, ip, C.c_int]
+    L.orc_random_free_space_pose.argtypes = [C.POINTER(FreeSpace), C.POINTER(C.c_uint64), dp]
+    L.orc_random_free_space_pose.restype = None
     L.orc_odom_update_action.argtypes = [C.c_int, dp, dp, dp, dp, dp, C.c_int, C.POINTER(C.c_uint64)]
     L.orc_odom_update_action.restype = None
     L.orc_pf_cluster_stats.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, ip, dp, dp, dp, dp, dp]
@@ -344,6 +353,18 @@ class ParticleFilter:
 
     def set_population_size_parameters(self, pop_err, pop_z):
         self.pf.pop_err, self.pf.pop_z = pop_err, pop_z
+
+    def set_random_pose_source(self, omap, non_free_space_radius):
+        """random_pose_fn_ = Node::randomFreeSpacePose over Node2D::updateFreeSpaceIndices of `omap`."""
+        m = omap.struct()
+        n = lib().orc_free_space_indices(C.byref(m), non_free_space_radius, None, 0)
+        self._free_ij = np.zeros((max(n, 1), 2), dtype=np.int32)
+        lib().orc_free_space_indices(C.byref(m), non_free_space_radius, _ip(self._free_ij), n)
+        self._free = FreeSpace(n, self._free_ij.ctypes.data_as(C.POINTER(C.c_int)), omap.size_x, omap.size_y,
+                               float(omap.origin[0]), float(omap.origin[1]), omap.resolution)
+        self._free_map = omap  # keep the arrays alive
+        self.pf.random_source = C.cast(C.pointer(self._free), C.c_void_p)
+        return n
 
     def set_resample_model(self, model):
         self.pf.resample_model = model

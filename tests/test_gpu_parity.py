@@ -222,8 +222,64 @@ def test_resample_kld_parameters_and_second_cycle(engine, orc):
         assert pf.getRngState() == opf.pf.rng
 
 
-def test_w_diff_positive_is_refused_loudly(engine, orc):
-    """Random-pose injection needs the node's callback; the device path reports it instead of
+@pytest.mark.parametrize("resampler", [0, 1])
+@pytest.mark.parametrize("n,device_kld", [(2500, False), (6000, True)])
+def test_recovery_random_poses_match_oracle(engine, orc, resampler, n, device_kld):
+    """w_diff > 0 (augmented-MCL recovery, particle_filter.cpp:295-324,383-388) with random_pose_fn_ =
+    Node::randomFreeSpacePose: which draws become random poses, the poses themselves (cell of
+    Node2D::updateFreeSpaceIndices + heading, bit for bit), the interleaved consumption of the drand48 stream, the
+    grown systematic count and the reset of w_slow / w_fast, against the oracle over three cycles."""
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    sc_ = Scenario(orc, size=200, n=n, beams=61, cloud="mixture")
+    engine.set_option(hpf.OPT_CDF_SERIAL, 1)
+    engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 1 if device_kld else 8192)
+    try:
+        m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf", min_samples=100, seed=31, alpha=(0.001, 0.1))
+        pf.setResampleModel(resampler)
+        pf.setRandomPoseGenerator(hpf.RANDOM_POSE_FREE_SPACE_2D)
+        opf = orc.ParticleFilter(100, n, 0.001, 0.1, 85.0, seed=31)
+        opf.set_resample_model(resampler)
+        opf.set_samples(sc_.samples)
+        n_free = opf.set_random_pose_source(sc_.omap, sc_.map_factors[2])
+        assert n_free > 1000
+        p = sc_.oracle_planar(61, "lf")
+        # scan 1 fits the map, scans 2 and 3 are progressively worse: w_fast falls below w_slow
+        scans = [sc_.ranges, np.clip(sc_.ranges * 0.6, 0.05, 29.0), np.full(61, 1.0)]
+        w_diffs = []
+        for cycle, ranges in enumerate(scans):
+            sc.updateSensor(pf, bpf.PlanarData(ranges, sc_.angles, sc_.range_max))
+            # the oracle scores the device's current set, so that only the resampling is under test
+            cur = pf.getCurrentSet()
+            st0 = pf.getState()
+            opf.set_samples(cur.samples, leaf_count=st0.leaf_count)
+            opf.pf.w_slow, opf.pf.w_fast = st0.w_slow, st0.w_fast
+            opf.pf.rng = pf.getRngState()
+            pf.updateResample()
+            out = opf.update_resample()
+            st1 = pf.getState()
+            w_diffs.append(out.w_diff)
+            assert out.status == 0, cycle
+            assert abs(st1.w_diff - out.w_diff) <= 1e-12
+            assert st1.sample_count == out.sample_count, (cycle, out.w_diff)
+            assert st1.leaf_count == out.leaf_count and st1.bin_count == out.node_count
+            M = out.sample_count
+            after = pf.getCurrentSet().samples
+            assert np.array_equal(after[:, :3], opf.samples[:M, :3])
+            assert np.all(after[:, 3] == 1.0 / M)
+            assert pf.getRngState() == opf.pf.rng
+            if out.w_diff > 0:
+                assert st1.w_slow == 0.0 and st1.w_fast == 0.0  # particle_filter.cpp:453-455
+                n_random = int((opf.last_idx < 0).sum())
+                assert n_random > 0
+        assert max(w_diffs) > 0.01  # the scenario really exercised the recovery branch
+    finally:
+        engine.set_option(hpf.OPT_CDF_SERIAL, 0)
+        engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 8192)
+
+
+def test_w_diff_positive_without_a_generator_is_refused_loudly(engine, orc):
+    """Without a random pose generator the recovery branch cannot run: the engine reports it instead of
     silently doing something else."""
     import badger_amcl_amd as bpf
     sc_ = Scenario(orc, size=200, n=500, beams=61)
