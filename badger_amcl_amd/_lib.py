@@ -96,6 +96,8 @@ SIGNATURES = {
     "bpf_cloud_apply_model_to_sample_set": (C.c_double, [_vp, _dp, C.c_int, C.POINTER(C.c_float), C.c_int, _ip]),
     "bpf_pf_update_sensor_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "bpf_shard_score_planar": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double]),
+    "bpf_shard_beam_counts_dev": (C.c_int, [_vp, C.POINTER(_vp), _ip]),
+    "bpf_shard_score_planar_finish": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_longlong]),
     "bpf_shard_score_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "bpf_shard_scalars_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "bpf_shard_normalize_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),

@@ -127,6 +127,20 @@ struct ScanSlot
   bool pending = false;
 };
 
+// host-side description of one staged scan (see stage_field_scan)
+struct FieldScan
+{
+  int n_valid = 0;             // beams that pass the range_max / NaN tests
+  int n_staged = 0;            // of those, the ones uploaded (all, or the kept ones of beam skipping)
+  bool copy_pending = false;   // pinned staging not yet copied to the device slot
+  int n_always_off = 0;        // valid beams too long / non-finite to stage: off the map for every pose
+  double off_map_term = 0.0;   // table[K]
+  int n_slots = 0;             // beam_ind range of the prob model
+  std::vector<int> slot_of;    // staged beam -> beam_ind
+  size_t beams_off = 0, table_off = 0, bytes = 0;
+  int table_len = 0;
+};
+
 }  // namespace
 
 struct bpf_engine
@@ -170,6 +184,8 @@ struct bpf_engine
     }
   } term_key;
   DevBuf<int> d_obs_count;
+  FieldScan skip_fs;          // staging of the counting pass of beam skipping, kept for its second half
+  bool skip_pending = false;
   // LDS-window scoring path
   DevBuf<double4> d_prep;
   DevBuf<double> d_prep_stats, d_chunk_partials;
@@ -479,19 +495,6 @@ int release_slot(bpf_engine* e, ScanSlot* s)
   return BPF_OK;
 }
 
-struct FieldScan
-{
-  int n_valid = 0;             // beams that pass the range_max / NaN tests
-  int n_staged = 0;            // of those, the ones uploaded (all, or the kept ones of beam skipping)
-  bool copy_pending = false;   // pinned staging not yet copied to the device slot
-  int n_always_off = 0;        // valid beams too long / non-finite to stage: off the map for every pose
-  double off_map_term = 0.0;   // table[K]
-  int n_slots = 0;             // beam_ind range of the prob model
-  std::vector<int> slot_of;    // staged beam -> beam_ind
-  size_t beams_off = 0, table_off = 0, bytes = 0;
-  int table_len = 0;
-};
-
 // Host half of calcLikelihoodFieldModel{,Prob,Gompertz}: beam decimation and validity
 // (planar_scanner.cpp:265-282, :339-343,410-425, :578-597) and the per-level term table.
 int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, int rc, double range_max,
@@ -783,10 +786,72 @@ int ensure_scalars(bpf_engine* e)
   return BPF_OK;
 }
 
+// Second half of beam skipping: mask from the (possibly shard-summed) counts in d_obs_count over
+// `n_total` particles, then pass 2 over this engine's `n` particles.
+int score_planar_beamskip_finish(bpf_engine* e, ParticlesDev p, int n, long long n_total, const double* ranges,
+                                 const double* angles, int rc, double range_max, bool* forced_zero, bool want_partials)
+{
+  const PlanarModel& pm = e->pm;
+  const FieldScan& fs = e->skip_fs;
+  e->skip_pending = false;
+  const int nv = std::max(fs.n_staged, 1);
+  std::vector<int> counts((size_t)nv, 0);
+  HIPCHK(e, hipMemcpyAsync(counts.data(), e->d_obs_count.p, (size_t)fs.n_staged * sizeof(int), hipMemcpyDeviceToHost,
+                           e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  std::vector<int> obs_count((size_t)pm.max_beams, 0);
+  for (int v = 0; v < fs.n_staged; ++v)
+    if (fs.slot_of[v] < pm.max_beams)
+      obs_count[fs.slot_of[v]] = counts[v];
+  std::vector<uint8_t> mask_slot((size_t)pm.max_beams, 0);
+  int skipped = 0;
+  for (int b = 0; b < pm.max_beams; ++b)
+  {
+    if ((obs_count[b] / (double)n_total) > pm.beam_skip_threshold)
+      mask_slot[b] = 1;
+    else
+      skipped++;
+  }
+  const bool error = skipped >= (pm.max_beams * pm.beam_skip_error_threshold);
+  // A kept slot that was never written holds 0.0 in the reference's scratch matrix, and
+  // log(0) = -inf zeroes every weight (planar_scanner.cpp:519-527).
+  std::vector<uint8_t> visited((size_t)pm.max_beams, 0);
+  for (int v = 0; v < fs.n_staged; ++v)
+    if (fs.slot_of[v] < pm.max_beams)
+      visited[fs.slot_of[v]] = 1;
+  bool poisoned = false;
+  for (int b = 0; b < pm.max_beams; ++b)
+    if ((error || mask_slot[b]) && !visited[b])
+      poisoned = true;
+  if (poisoned)
+  {
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, p.w, 0.0, n);
+    HIPCHK(e, hipGetLastError());
+    *forced_zero = true;
+    return BPF_OK;
+  }
+  // pass 2: stage only the kept beams (all of them when the error switch tripped) and score
+  std::vector<uint8_t> keep((size_t)std::max(fs.n_slots, pm.max_beams), 0);
+  for (size_t b = 0; b < keep.size(); ++b)
+    keep[b] = error ? 1 : ((int)b < pm.max_beams ? mask_slot[b] : 0);
+  ScanSlot* s2 = nullptr;
+  FieldScan fs2;
+  int rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s2, &fs2, &keep);
+  if (rcode != BPF_OK)
+    return rcode;
+  rcode = launch_field(e, p, n, s2, fs2, nullptr, 0, want_partials);
+  if (rcode != BPF_OK)
+    return rcode;
+  return release_slot(e, s2);
+}
+
 // Scores `n` particles of `p` with the configured planar model (+ recalcWeight).  Leaves the
-// weights un-normalised.  set_converged feeds the prob model's beam-skip switch.
+// weights un-normalised.  set_converged feeds the prob model's beam-skip switch.  defer_beamskip_pass2: stop
+// after the counting pass of beam skipping (e->skip_pending is then set) so that a sharded driver can sum the
+// counts over the shards before score_planar_beamskip_finish.
 int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const double* ranges,
-                 const double* angles, int rc, double range_max, bool* forced_zero, bool want_partials = false)
+                 const double* angles, int rc, double range_max, bool* forced_zero, bool want_partials = false,
+                 bool defer_beamskip_pass2 = false)
 {
   *forced_zero = false;
   e->fused_partials = 0;
@@ -921,54 +986,11 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
   rcode = release_slot(e, s);
   if (rcode != BPF_OK)
     return rcode;
-  std::vector<int> counts((size_t)nv, 0);
-  HIPCHK(e, hipMemcpyAsync(counts.data(), e->d_obs_count.p, (size_t)fs.n_staged * sizeof(int), hipMemcpyDeviceToHost,
-                           e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  std::vector<int> obs_count((size_t)pm.max_beams, 0);
-  for (int v = 0; v < fs.n_staged; ++v)
-    if (fs.slot_of[v] < pm.max_beams)
-      obs_count[fs.slot_of[v]] = counts[v];
-  std::vector<uint8_t> mask_slot((size_t)pm.max_beams, 0);
-  int skipped = 0;
-  for (int b = 0; b < pm.max_beams; ++b)
-  {
-    if ((obs_count[b] / (double)n) > pm.beam_skip_threshold)
-      mask_slot[b] = 1;
-    else
-      skipped++;
-  }
-  const bool error = skipped >= (pm.max_beams * pm.beam_skip_error_threshold);
-  // A kept slot that was never written holds 0.0 in the reference's scratch matrix, and
-  // log(0) = -inf zeroes every weight (planar_scanner.cpp:519-527).
-  std::vector<uint8_t> visited((size_t)pm.max_beams, 0);
-  for (int v = 0; v < fs.n_staged; ++v)
-    if (fs.slot_of[v] < pm.max_beams)
-      visited[fs.slot_of[v]] = 1;
-  bool poisoned = false;
-  for (int b = 0; b < pm.max_beams; ++b)
-    if ((error || mask_slot[b]) && !visited[b])
-      poisoned = true;
-  if (poisoned)
-  {
-    hipLaunchKernelGGL(k_fill, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, p.w, 0.0, n);
-    HIPCHK(e, hipGetLastError());
-    *forced_zero = true;
-    return BPF_OK;
-  }
-  // pass 2: stage only the kept beams (all of them when the error switch tripped) and score
-  std::vector<uint8_t> keep((size_t)std::max(fs.n_slots, pm.max_beams), 0);
-  for (size_t b = 0; b < keep.size(); ++b)
-    keep[b] = error ? 1 : ((int)b < pm.max_beams ? mask_slot[b] : 0);
-  ScanSlot* s2 = nullptr;
-  FieldScan fs2;
-  rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s2, &fs2, &keep);
-  if (rcode != BPF_OK)
-    return rcode;
-  rcode = launch_field(e, p, n, s2, fs2, nullptr, 0);
-  if (rcode != BPF_OK)
-    return rcode;
-  return release_slot(e, s2);
+  e->skip_fs = fs;
+  e->skip_pending = true;
+  if (defer_beamskip_pass2)
+    return BPF_OK;  // sharded: the per-beam counts are summed over the shards first
+  return score_planar_beamskip_finish(e, p, n, n, ranges, angles, rc, range_max, forced_zero, want_partials);
 }
 
 int fetch_scalars(bpf_engine* e)
@@ -3164,6 +3186,26 @@ int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_poi
 }
 
 // ---------------------------------------------------------------------- sharded stages
+namespace
+{
+// local weight total into scalars[0] after a sharded scoring stage
+int shard_local_total(bpf_engine* e)
+{
+  SampleSet& s = e->sets[e->cur];
+  if (e->fused_partials > 0)
+  {
+    // the scoring kernel left per-block partials: one small launch folds them into the local total
+    ProfScope ps(e, BPF_K_REDUCE);
+    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
+                       e->fused_partials, e->d_scalars.p, 0);
+    HIPCHK(e, hipGetLastError());
+    e->fused_partials = 0;
+    return BPF_OK;
+  }
+  return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
+}
+}  // namespace
+
 int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
                            double range_max)
 {
@@ -3176,21 +3218,42 @@ int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* an
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
   bool forced_zero = false;
+  e->skip_pending = false;
   int rc = score_planar(e, s.dev(), e->sample_count, e->converged, ranges, angles, range_count, range_max,
-                        &forced_zero, true);
+                        &forced_zero, true, true);
   if (rc != BPF_OK)
     return rc;
-  if (e->fused_partials > 0)
-  {
-    // the scoring kernel left per-block partials: one small launch folds them into the local total
-    ProfScope ps(e, BPF_K_REDUCE);
-    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
-                       e->fused_partials, e->d_scalars.p, 0);
-    HIPCHK(e, hipGetLastError());
-    e->fused_partials = 0;
-    return BPF_OK;
-  }
-  return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
+  if (e->skip_pending)
+    return BPF_SHARD_NEED_BEAM_COUNTS;  // sum bpf_shard_beam_counts_dev over the shards, then ..._finish
+  return shard_local_total(e);
+}
+
+int bpf_shard_beam_counts_dev(bpf_engine* e, void** counts_dev, int* n_counts)
+{
+  if (!e || !counts_dev || !n_counts)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->skip_pending)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no beam-skip counting pass is pending");
+  *counts_dev = e->d_obs_count.p;
+  *n_counts = std::max(e->skip_fs.n_staged, 1);
+  return BPF_OK;
+}
+
+int bpf_shard_score_planar_finish(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                                  double range_max, long long global_count)
+{
+  if (!e || !ranges || !angles || global_count <= 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf || !e->skip_pending)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no beam-skip counting pass is pending");
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& s = e->sets[e->cur];
+  bool forced_zero = false;
+  int rc = score_planar_beamskip_finish(e, s.dev(), e->sample_count, global_count, ranges, angles, range_count,
+                                        range_max, &forced_zero, true);
+  if (rc != BPF_OK)
+    return rc;
+  return shard_local_total(e);
 }
 
 int bpf_shard_score_cloud(bpf_engine* e, const float* points_xyz, int n_points)

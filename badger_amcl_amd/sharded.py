@@ -55,9 +55,22 @@ class HipShardBackend:
             e.check(lib.bpf_shard_score_cloud(e.h, data.points_.ctypes.data_as(C.POINTER(C.c_float)),
                                               data.points_.shape[0]))
             return
-        e.check(lib.bpf_shard_score_planar(e.h, data.ranges_.ctypes.data_as(C.POINTER(C.c_double)),
-                                           data.angles_.ctypes.data_as(C.POINTER(C.c_double)), data.range_count_,
-                                           data.range_max_))
+        rc = lib.bpf_shard_score_planar(e.h, data.ranges_.ctypes.data_as(C.POINTER(C.c_double)),
+                                        data.angles_.ctypes.data_as(C.POINTER(C.c_double)), data.range_count_,
+                                        data.range_max_)
+        if rc != 100:  # BPF_SHARD_NEED_BEAM_COUNTS
+            e.check(rc)
+            return None
+        # beam skipping: the per-beam agreement counts have to be summed over the shards first
+        p, n = C.c_void_p(), C.c_int()
+        e.check(lib.bpf_shard_beam_counts_dev(e.h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DevArray(p.value, (n.value,), "<i4"), device=self.device)
+
+    def score_finish(self, data, global_n):
+        e = self.e
+        e.check(e.lib.bpf_shard_score_planar_finish(e.h, data.ranges_.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    data.angles_.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    data.range_count_, data.range_max_, int(global_n)))
 
     def local_total(self):
         return self.scalars[0:1]
@@ -231,7 +244,11 @@ class ShardedFilter:
 
     # ---- Seam A
     def update_sensor(self, data):
-        self.b.score(data)
+        counts = self.b.score(data)
+        if counts is not None:
+            # prob model with beam skipping: one extra all-reduce of max_beams int32 between its two passes
+            self._all_reduce_sum(counts)
+            self.b.score_finish(data, self.sample_count)
         self.totals = self._all_gather(self.b.local_total())
         self.b.normalize(self.totals, self.sample_count)
 

@@ -295,6 +295,15 @@ int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_poi
 /* score + recalcWeight on the local shard; the local weight total lands in scalars[0] */
 int bpf_shard_score_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
                            double range_max);
+/* Beam skipping of the prob model (planar_scanner.cpp:352-395,482-529) needs, per beam, the number of particles
+ * of the WHOLE set that agree with it.  When it is active (model prob, do_beamskip, set converged)
+ * bpf_shard_score_planar stops after the counting pass and returns BPF_SHARD_NEED_BEAM_COUNTS (> 0, not an error):
+ * sum the int32 counts of bpf_shard_beam_counts_dev over the shards in place (all-reduce), then call
+ * bpf_shard_score_planar_finish with the same scan and the global particle count. */
+#define BPF_SHARD_NEED_BEAM_COUNTS 100
+int bpf_shard_beam_counts_dev(bpf_engine* e, void** counts_dev, int* n_counts);
+int bpf_shard_score_planar_finish(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                                  double range_max, long long global_count);
 /* the same for the 3-D path (PointCloudScanner::applyModelToSampleSet on the local shard) */
 int bpf_shard_score_cloud(bpf_engine* e, const float* points_xyz, int n_points);
 /* device address of the engine's scalar block, double[16]: [0] local weight total,

@@ -188,3 +188,81 @@ def test_two_ranks_cloud3d_equal_single_engine(tmp_path):
     merged = np.concatenate([recs[0]["samples"], recs[1]["samples"]])
     assert np.array_equal(merged[:, :3], pf.getCurrentSet().samples[:, :3])
     e.close()
+
+
+BEAMSKIP = dict(do_beamskip=1, beam_skip_distance=0.5, beam_skip_threshold=0.3, beam_skip_error_threshold=0.9)
+
+
+def _beamskip_scenario():
+    from oracle import pyoracle as orc
+    from scenario import Scenario
+    sc = Scenario(orc, size=200, n=3000, beams=60, cloud="converged", frac_max=0.0, frac_nan=0.0)
+    # a tight cloud: the first resample reports "converged", which arms beam skipping for the second update
+    from badger_amcl_amd import synth
+    sc.samples = synth.converged_cloud(3000, sc.pose, seed=12, sigma=(0.05, 0.05, 0.02))
+    return orc, sc
+
+
+def _beamskip_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import badger_amcl_amd as bpf
+    from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+    from scenario import Scenario
+    orc, sc = _beamskip_scenario()
+    n = sc.samples.shape[0]
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    e = bpf.Engine(0)
+    shard = Scenario.__new__(Scenario)
+    shard.__dict__.update(sc.__dict__)
+    shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
+    m, scn, pf, data = shard.gpu_objects(e, 60, "prob", min_samples=100, max_samples=n, seed=3, model_kw=BEAMSKIP)
+    sf = ShardedFilter(HipShardBackend(e, scn, pf, torch.device("cuda", 0)), dist, first_window=1024)
+    recs = []
+    for cycle in range(2):
+        sf.update_sensor(data)
+        w_after = pf.getCurrentSet().samples.copy()
+        sf.update_resample()
+        st = sf.state()
+        recs.append(dict(w=w_after, samples=pf.getCurrentSet().samples.copy(), M=st.sample_count, conv=st.converged,
+                         rng=pf.getRngState()))
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(recs, dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    e.close()
+
+
+def test_two_ranks_prob_model_with_beam_skipping(tmp_path):
+    """The prob model's beam skipping needs per-beam agreement counts over the WHOLE set: one all-reduce of the
+    int32 counts between its two passes (bpf_shard_beam_counts_dev / bpf_shard_score_planar_finish)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_beamskip_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
+    import badger_amcl_amd as bpf
+    orc, sc = _beamskip_scenario()
+    n = sc.samples.shape[0]
+    e = bpf.Engine(0)
+    m, scn, pf, data = sc.gpu_objects(e, 60, "prob", min_samples=100, max_samples=n, seed=3, model_kw=BEAMSKIP)
+    for cycle in range(2):
+        if cycle == 1:
+            assert pf.getState().converged == 1  # beam skipping is armed for this update
+        scn.updateSensor(pf, data)
+        w_ref = pf.getCurrentSet().samples[:, 3].copy()
+        pf.updateResample()
+        st = pf.getState()
+        r0, r1 = recs[0][cycle], recs[1][cycle]
+        w_sh = np.concatenate([r0["w"][:, 3], r1["w"][:, 3]])
+        assert np.allclose(w_sh, w_ref, rtol=1e-12, atol=0)
+        for r in (r0, r1):
+            assert r["M"] == st.sample_count and r["rng"] == pf.getRngState() and r["conv"] == st.converged
+        merged = np.concatenate([r0["samples"], r1["samples"]])
+        assert np.array_equal(merged[:, :3], pf.getCurrentSet().samples[:, :3])
+    e.close()
