@@ -159,6 +159,53 @@ def cpu_baseline(args, wl, lut, budget_s):
         mean_cells, opf
 
 
+def cpu_baseline_all_cores(args, wl, lut):
+    """SURVEY.md section 8(d)'s generous figure: the same oracle with the scoring loop sharded over every host
+    core of a one-GPU job's share (at most 16; contiguous particle ranges, one thread each; ctypes releases the GIL), then the
+    serial normalisation and resampler.  One whole step."""
+    import threading
+    from badger_amcl_amd import synth
+    from oracle import pyoracle as orc
+    if args.model not in ("lf", "gompertz"):
+        return None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))  # a one-GPU job's share of the host (the box runs one job per GPU)
+    omap = orc.OccupancyMap(wl["cells"], 0.05, wl["origin"], 2.0, lut)
+    kw = synth.LF_DEFAULTS if args.model == "lf" else synth.GOMPERTZ_LAUNCH
+    mid = orc.MODEL_LF if args.model == "lf" else orc.MODEL_LF_GOMPERTZ
+    n = wl["n"]
+    opf = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0, seed=42)
+    opf.set_resample_model(1 if args.resampler == "systematic" else 0)
+    opf.set_samples(wl["samples"][:n], leaf_count=0)
+    bounds = [(n * t) // cores for t in range(cores + 1)]
+    totals = [0.0] * cores
+
+    def work(t, view):
+        p = orc.planar(mid, wl["beams"], scanner_pose=synth.SCANNER_POSE, **kw)
+        p.off_map_factor, p.non_free_space_factor, p.non_free_space_radius = synth.MAP_FACTORS
+        totals[t] = orc.planar_apply(p, omap, view, wl["ranges"], wl["angles"], 30.0, 0, None)
+
+    def sensor(samples, conv):
+        th = [threading.Thread(target=work, args=(t, samples[bounds[t]:bounds[t + 1]])) for t in range(cores)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        total = 0.0
+        for v in totals:
+            total += v
+        return total
+
+    t0 = time.perf_counter()
+    opf.update_sensor(sensor)
+    out = opf.update_resample()
+    dt = time.perf_counter() - t0
+    return dict(value=float(n) * wl["beams"] / dt, unit="particle-beam evals/s", cores=cores, kind="port",
+                sample="1 step of %d particles x %d beams, scoring on %d threads (contiguous particle ranges), serial "
+                       "normalise + resample, %.2f s; resampled to M=%d" % (n, wl["beams"], cores, dt,
+                                                                            out.sample_count))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,8 +325,22 @@ def main():
 
     if rank == 0:
         cpu, mean_cells = None, None
+        cpu_all, host_path = None, None
         if world == 1 and args.cpu_budget > 0:
             cpu, mean_cells, _ = cpu_baseline(args, wl, lut, args.cpu_budget)
+            cpu_all = cpu_baseline_all_cores(args, wl, lut)
+        if world == 1 and dist is None and args.model != "cloud3d":
+            # Seam A with host buffers (PlanarScanner::applyModelToSampleSet): H2D of the set, scoring, D2H of the
+            # weights inside every call -- the PCIe-inclusive figure, never `value`
+            host_samples = wl["samples"].copy()
+            sc.applyModelToSampleSet(data, host_samples, 0)
+            t0h = time.perf_counter()
+            for _ in range(10):
+                host_samples[:, 3] = wl["samples"][:, 3]
+                sc.applyModelToSampleSet(data, host_samples, 0)
+            dth = (time.perf_counter() - t0h) / 10
+            host_path = {"ms_per_update": dth * 1e3, "evals_per_s": float(wl["n"]) * wl["beams"] / dth,
+                         "what": "applyModelToSampleSet with host buffers: 3.2 MB H2D + scoring + 3.2 MB D2H per call"}
         score = prof["score"]
         k_ms = score["ms"] / max(score["launches"], 1)
         if args.model == "beam":
@@ -318,6 +379,8 @@ def main():
                          "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
                          "launches_timed": int(score["launches"])},
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
+            "host_buffer_path": host_path,
             "kernel_ms_per_step": {k: v["ms"] / n_all for k, v in prof_all.items() if v["launches"]},
         }
         if mean_cells is not None:
