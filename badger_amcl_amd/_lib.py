@@ -111,6 +111,8 @@ SIGNATURES = {
     "bpf_kld_reset": (C.c_int, [_vp]),
     "bpf_kld_feed": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "bpf_kld_feed_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _ip]),
+    "bpf_shard_begin_resample": (C.c_int, [_vp, C.c_uint64, C.c_int, _dp, _ip]),
+    "bpf_shard_end_resample": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),
     "bpf_pf_resample_limit": (C.c_int, [_vp, C.c_int, _ip]),
     "bpf_shard_systematic_window_dev": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp,
                                                   C.c_int, _vp]),

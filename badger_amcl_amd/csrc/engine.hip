@@ -263,6 +263,10 @@ struct bpf_engine
   int n_free = 0;
   int free_map_version = -1;
   double free_radius = -1.0;
+  double shard_w_diff = 0.0;        // of the sharded resample in progress (bpf_shard_begin_resample)
+  bool shard_chain = false;         // its draw chain is in d_chain
+  int shard_n_random = 0;           // systematic: random poses at the head of the new set
+  uint64_t shard_rng0 = 0;
   DevBuf<uint64_t> d_chain_bits;
   DevBuf<int> d_chain_cnt, d_chain_exit, d_chain_entry, d_chain_base, d_chain;
   PinnedBuf<int> h_chain_word;
@@ -3340,6 +3344,17 @@ int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m
   A.window = static_cast<long long*>(window_dev);
   A.stride = stride;
   A.flags = static_cast<int*>(flags_dev);
+  if (e->shard_chain)
+  {
+    // w_diff > 0 (bpf_shard_begin_resample built the chain from this same stream state)
+    if (rng_state48 != e->shard_rng0 || m1 > e->max_samples)
+      return e->fail(BPF_ERR_INVALID_ARGUMENT, "draw window does not belong to the resample begun");
+    A.chain = e->d_chain.p;
+    A.write_random = rank == 0;
+    int rcf = ensure_free_space(e, &A.free_space);
+    if (rcf != BPF_OK)
+      return rcf;
+  }
   ProfScope ps(e, BPF_K_DRAW);
   hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(m1 - m0, 256)), dim3(256), 0, e->stream, A);
   HIPCHK(e, hipGetLastError());
@@ -3494,6 +3509,90 @@ int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_ke
   return bpf_kld_feed(e, e->h_keys.p, 0, n_keys, n_keys, first_draw_index, stop_count_out);
 }
 
+int bpf_shard_begin_resample(bpf_engine* e, uint64_t rng_state48, int leaf_count, double* w_diff_out,
+                             int* systematic_count_out)
+{
+  if (!e || !w_diff_out || !systematic_count_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  // w_diff = max(0, 1 - w_fast / w_slow) (particle_filter.cpp:438-440); the averages are the same on every shard
+  double w_diff = 0.0;
+  if (e->alpha_slow != 0.0 || e->alpha_fast != 0.0)
+  {
+    int rc = fetch_scalars(e);
+    if (rc != BPF_OK)
+      return rc;
+    w_diff = 1.0 - e->h_scalars.p->v[2] / e->h_scalars.p->v[1];
+    if (!(w_diff >= 0.0))
+      w_diff = 0.0;
+  }
+  e->w_diff_last = w_diff;
+  e->shard_w_diff = w_diff;
+  e->shard_chain = false;
+  e->shard_n_random = 0;
+  e->shard_rng0 = rng_state48 & ((1ull << 48) - 1);
+  int count = resample_limit(leaf_count, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+  if (w_diff > 0.0)
+  {
+    if (e->resample_model == BPF_RESAMPLE_SYSTEMATIC)
+    {
+      count *= (1.0 + w_diff);  // :295-306
+      if (count > e->max_samples)
+        count = e->max_samples;
+      e->shard_n_random = (int)(w_diff * count);
+    }
+    else
+    {
+      FreeSpaceDev fs{};
+      int rc = ensure_free_space(e, &fs);
+      if (rc != BPF_OK)
+        return rc;
+      const uint64_t keep = e->rng;
+      e->rng = e->shard_rng0;
+      rc = build_draw_chain(e, w_diff, e->max_samples);
+      e->rng = keep;
+      if (rc != BPF_OK)
+        return rc;
+      e->shard_chain = true;
+    }
+  }
+  *w_diff_out = w_diff;
+  *systematic_count_out = count;
+  return BPF_OK;
+}
+
+int bpf_shard_end_resample(bpf_engine* e, int sample_count, uint64_t* rng_state48_out)
+{
+  if (!e || !rng_state48_out || sample_count <= 0)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  uint64_t consumed;
+  if (e->resample_model == BPF_RESAMPLE_SYSTEMATIC)
+    consumed = 1ull + 2ull * (uint64_t)e->shard_n_random;
+  else if (e->shard_chain)
+  {
+    if (sample_count > e->max_samples)
+      return e->fail(BPF_ERR_INVALID_ARGUMENT, "sample_count beyond the chain");
+    HIPCHK(e, e->h_chain_word.reserve(1));
+    HIPCHK(e, hipMemcpyAsync(e->h_chain_word.p, e->d_chain.p + sample_count, sizeof(int), hipMemcpyDeviceToHost,
+                             e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    consumed = (uint64_t)((unsigned)e->h_chain_word.p[0] & 0x7fffffffu) - 1ull;
+  }
+  else
+    consumed = 2ull * (uint64_t)sample_count;
+  *rng_state48_out = lcg_skip_host(e->shard_rng0, consumed, e->jump);
+  if (e->shard_w_diff > 0.0)  // particle_filter.cpp:453-455
+    HIPCHK(e, hipMemsetAsync(&e->d_scalars.p->v[1], 0, 2 * sizeof(double), e->stream));
+  e->shard_chain = false;
+  e->shard_n_random = 0;
+  return BPF_OK;
+}
+
 int bpf_pf_resample_limit(bpf_engine* e, int leaf_count, int* count_out)
 {
   if (!e || !count_out)
@@ -3516,10 +3615,14 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
   // the reference's serial chain (particle_filter.cpp:337-341): target += delta, -= 1 once it passes 1
   const uint64_t st = lcg_skip_host(rng_state48 & ((1ull << 48) - 1), 1, e->jump);
   double t = std::ldexp((double)st, -48);
-  const double delta = 1.0 / count;
+  const int n_random = e->shard_n_random;
+  if (n_random < 0 || n_random >= count)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "systematic window: random pose count out of range");
+  const int n_systematic = count - n_random;
+  const double delta = 1.0 / n_systematic;
   if (e->targets_read)  // a previous window kernel may still be reading the pinned targets
     HIPCHK(e, hipEventSynchronize(e->targets_read));
-  for (int i = 0; i < count; ++i)
+  for (int i = 0; i < n_systematic; ++i)
   {
     e->h_targets.p[i] = t;
     t += delta;
@@ -3536,8 +3639,16 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
   A.world = world;
   A.m0 = 0;
   A.m1 = count;
-  A.rng_state = 0;
+  A.rng_state = rng_state48 & ((1ull << 48) - 1);
   A.jump = e->jump;
+  A.n_random = n_random;
+  A.write_random = rank == 0;
+  if (n_random > 0)
+  {
+    int rcf = ensure_free_space(e, &A.free_space);
+    if (rcf != BPF_OK)
+      return rcf;
+  }
   A.window = static_cast<long long*>(window_dev);
   A.stride = stride;
   A.flags = static_cast<int*>(flags_dev);

@@ -735,7 +735,13 @@ struct WindowArgs
   long long* window;     // [6][stride]
   int stride;
   int* flags;
-  const double* targets; // systematic resampling: r of draw m is targets[m] (nullptr: the drand48 stream)
+  const double* targets; // systematic resampling: r of draw m is targets[m - n_random] (nullptr: the drand48 stream)
+  // w_diff > 0: `chain` as in DrawArgs (multinomial), or the first n_random samples (systematic) are random
+  // free-space poses; they are written by the shard with write_random set, so the window sum holds them once
+  const int* chain;
+  int n_random;
+  int write_random;
+  FreeSpaceDev free_space;
 };
 
 __global__ void k_draw_window(const WindowArgs A)
@@ -759,13 +765,55 @@ __global__ void k_draw_window(const WindowArgs A)
   for (int r = 0; r < A.rank; ++r)
     offset += A.sums_are_totals ? A.sums[r] / T : A.sums[r];
   const double top = offset + (A.sums_are_totals ? A.sums[A.rank] / T : A.sums[A.rank]);
-  double r;
+  double r = 0.0;
+  bool random = false;
+  double rx = 0.0, ry = 0.0, rth = 0.0;
   if (A.targets != nullptr)
-    r = A.targets[m];
+  {
+    if (m < A.n_random)
+    {
+      random = true;  // particle_filter.cpp:316-324: stream elements 2m+2, 2m+3 (element 1 is the start)
+      const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
+      random_free_space_pose(A.free_space, ldexp((double)xs, -48), ldexp((double)lcg_next(xs), -48), &rx, &ry, &rth);
+    }
+    else
+      r = A.targets[m - A.n_random];
+  }
+  else if (A.chain != nullptr)
+  {
+    const int c = A.chain[m];
+    const uint64_t xs = lcg_skip(A.rng_state, (uint64_t)(c & 0x7fffffff) + 1ull, A.jump);
+    if (c < 0)
+    {
+      random = true;  // :385-388
+      random_free_space_pose(A.free_space, ldexp((double)xs, -48), ldexp((double)lcg_next(xs), -48), &rx, &ry, &rth);
+    }
+    else
+      r = ldexp((double)xs, -48);
+  }
   else
   {
     const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
     r = ldexp((double)xs, -48);
+  }
+  if (random)
+  {
+    long long out[6] = { 0, 0, 0, 0, 0, 0 };
+    if (A.write_random)
+    {
+      int key[3];
+      pose_key(rx, ry, rth, key);
+      out[0] = __double_as_longlong(rx);
+      out[1] = __double_as_longlong(ry);
+      out[2] = __double_as_longlong(rth);
+      out[3] = key[0];
+      out[4] = key[1];
+      out[5] = key[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      A.window[(size_t)k * A.stride + o] = out[k];
+    return;
   }
   const bool last = A.rank == A.world - 1;
   const bool mine = (r >= offset) && (r < top || last);

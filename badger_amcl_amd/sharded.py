@@ -11,6 +11,8 @@ xGMI) carries the three small exchanges the path really has:
                    gathered by the sensor update (slice_q = total_q / sum(totals), the same quotient on
                    every rank), so no further exchange is needed; only when the weights were set by
                    something else than update_sensor are the W local CDF sums all-gathered instead.
+                   Recovery draws (w_diff > 0): every rank resolves the same draw chain and shard 0 writes
+                   the random free-space poses -- no further exchange.
 
 Scoring itself shards with no communication.  The KLD stop rule (an ordered kd-tree replay) runs
 redundantly on every rank from the assembled key window, so all ranks agree on the sample count
@@ -121,6 +123,19 @@ class HipShardBackend:
 
     def resample_model(self):
         return self.pf.resample_model
+
+    def begin_resample(self, rng, leaf_count):
+        """(w_diff, systematic count); resolves the draw chain when w_diff > 0 (multinomial)."""
+        w, c = C.c_double(), C.c_int()
+        self.e.check(self.e.lib.bpf_shard_begin_resample(self.e.h, C.c_uint64(rng), int(leaf_count), C.byref(w),
+                                                         C.byref(c)))
+        return w.value, c.value
+
+    def end_resample(self, m):
+        """drand48 state after m samples; resets the averages when w_diff > 0."""
+        out = C.c_uint64()
+        self.e.check(self.e.lib.bpf_shard_end_resample(self.e.h, int(m), C.byref(out)))
+        return out.value
 
     def resample_limit(self, leaf_count):
         out = C.c_int()
@@ -273,13 +288,13 @@ class ShardedFilter:
     # ---- Seam B, systematic (particle_filter.cpp:269-354, w_diff == 0)
     def _update_resample_systematic(self):
         b, W = self.b, self.world
-        count = b.resample_limit(self._global_leaf_count())
+        rng = b.rng_state()
+        w_diff, count = b.begin_resample(rng, self._global_leaf_count())
         b.build_cdf(self.flags)
         if self.totals is not None:
             sums, sums_are_totals = self.totals, True
         else:
             sums, sums_are_totals = self._all_gather(b.local_sum()), False
-        rng = b.rng_state()
         window = self._windows.get((count, "sys"))
         if window is None:
             window = torch.zeros((6, count), dtype=torch.int64, device=self.device)
@@ -297,7 +312,7 @@ class ShardedFilter:
         else:
             b.adopt(pose[0, lo:hi], pose[1, lo:hi], pose[2, lo:hi], hi - lo, M, leaf, bins)
             b.converged(pose[0, :M], pose[1, :M], M)
-        b.set_rng_state(b.skip(rng, 1))
+        b.set_rng_state(b.end_resample(M))
         self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
         self.sample_count = M
         self.leaf_count, self.bin_count = leaf, bins
@@ -315,6 +330,7 @@ class ShardedFilter:
         else:
             sums, sums_are_totals = self._all_gather(b.local_sum()), False
         rng = b.rng_state()
+        b.begin_resample(rng, self.leaf_count)  # w_diff; with w_diff > 0 the draws follow the resolved chain
         b.kld_reset()
         m0, stop = 0, -1
         win = max(1024, min(self.window_hint, self.max_global))
@@ -367,7 +383,7 @@ class ShardedFilter:
                 self.out[:, w0:w0 + cnt] = window[0:3].view(torch.float64)
             b.adopt(self.out[0, lo:hi], self.out[1, lo:hi], self.out[2, lo:hi], hi - lo, M, leaf, bins)
             b.converged(self.out[0, :M], self.out[1, :M], M)
-        b.set_rng_state(b.skip(rng, 2 * M))
+        b.set_rng_state(b.end_resample(M))
         self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
         self.sample_count = M
         self.leaf_count, self.bin_count = leaf, bins

@@ -353,11 +353,21 @@ int bpf_kld_feed(bpf_engine* e, const void* keys, int keys_are_int64, int stride
  * generation word the host spins on (no D2H copy call, no stream synchronisation), then the replay runs. */
 int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_keys, int first_draw_index,
                      int* stop_count_out);
-/* Systematic resampling over shards (particle_filter.cpp:269-354 with w_diff == 0): the targets
+/* Brackets of a sharded resample.  begin: w_diff = max(0, 1 - w_fast / w_slow) from the engine's averages (the
+ * same on every shard); for the multinomial resampler with w_diff > 0 it resolves where every candidate draw finds
+ * its stream elements (kernels_recovery.hpp) -- bpf_shard_draw_window_dev then follows that chain and shard 0
+ * writes the random free-space poses; *systematic_count_out = resampleLimit(leaf_count), grown by (1 + w_diff)
+ * (particle_filter.cpp:295-306), the `count` to pass to bpf_shard_systematic_window_dev, whose first
+ * int(w_diff * count) samples are random poses.  end: the drand48 state after `sample_count` samples, and the
+ * reset of the averages when w_diff > 0 (:453-455).  Needs bpf_pf_set_random_pose_generator when w_diff > 0. */
+int bpf_shard_begin_resample(bpf_engine* e, uint64_t rng_state48, int leaf_count, double* w_diff_out,
+                             int* systematic_count_out);
+int bpf_shard_end_resample(bpf_engine* e, int sample_count, uint64_t* rng_state48_out);
+/* Systematic resampling over shards (particle_filter.cpp:269-354): the targets
  * start + m / count are formed on the host exactly as the reference's serial chain, every shard resolves the
  * targets that fall into its slice of the global CDF and writes pose bits + key into its window columns
- * (zeros elsewhere), as bpf_shard_draw_window_dev does for the multinomial draws.  count =
- * bpf_pf_resample_limit(leaf count of the current GLOBAL set); rng_state48 = state BEFORE the one drand48. */
+ * (zeros elsewhere), as bpf_shard_draw_window_dev does for the multinomial draws.  count = what
+ * bpf_shard_begin_resample returned; rng_state48 = state BEFORE the one drand48. */
 int bpf_pf_resample_limit(bpf_engine* e, int leaf_count, int* count_out);
 int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int count, const void* sums_dev,
                                     int sums_are_totals, int rank, int world, void* window_dev, int stride,

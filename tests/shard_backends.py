@@ -83,19 +83,63 @@ class OracleShardBackend:
     def resample_model(self):
         return self._resample_model
 
+    def begin_resample(self, rng, leaf_count):
+        pf = self.pfh.pf
+        w_diff = 1.0 - pf.w_fast / pf.w_slow if pf.w_slow != 0.0 else float("nan")
+        if not w_diff >= 0.0:
+            w_diff = 0.0
+        self._w_diff, self._rng0, self._chain, self._n_random = w_diff, rng, None, 0
+        count = self.pfh.resample_limit(leaf_count)
+        if w_diff > 0.0:
+            if self._resample_model == 1:
+                count = min(int(count * (1.0 + w_diff)), self._max)
+                self._n_random = int(w_diff * count)
+            else:
+                # where every candidate draw finds its stream elements (serial walk; the product resolves it in
+                # parallel): (position of the test element, random?)
+                chain, q = [], 1
+                for _ in range(self._max + 1):
+                    rnd = lcg_skip(rng, q) / float(1 << 48) < w_diff
+                    chain.append((q, rnd))
+                    q += 3 if rnd else 2
+                self._chain = chain
+        return w_diff, count
+
+    def end_resample(self, m):
+        if self._resample_model == 1:
+            consumed = 1 + 2 * self._n_random
+        elif self._chain is not None:
+            consumed = self._chain[m][0] - 1
+        else:
+            consumed = 2 * m
+        if self._w_diff > 0.0:
+            self.pfh.pf.w_slow = self.pfh.pf.w_fast = 0.0
+        return lcg_skip(self._rng0, consumed)
+
+    def _random_pose(self, state_before_first):
+        """Node::randomFreeSpacePose from the two stream elements after `state_before_first`."""
+        import ctypes as C
+        st = C.c_uint64(state_before_first)
+        pose = np.zeros(3)
+        self.orc.lib().orc_random_free_space_pose(C.byref(self.pfh._free), C.byref(st),
+                                                  pose.ctypes.data_as(C.POINTER(C.c_double)))
+        return pose
+
     def resample_limit(self, leaf_count):
         return self.pfh.resample_limit(leaf_count)
 
     def systematic_window(self, rng, count, sums, sums_are_totals, rank, world, window, flags):
         start = lcg_skip(rng, 1) / float(1 << 48)
-        delta = 1.0 / count
-        targets, t = [], start
-        for _ in range(count):
+        n_random = self._n_random
+        delta = 1.0 / (count - n_random)
+        targets, t = [None] * n_random, start
+        for _ in range(count - n_random):
             targets.append(t)
             t += delta
             if t > 1.0:
                 t -= 1.0
-        self._fill_window(targets, 0, sums, sums_are_totals, rank, world, window, flags)
+        random = {m: lcg_skip(rng, 2 * m + 1) for m in range(n_random)}  # state before elements 2m+2, 2m+3
+        self._fill_window(targets, 0, sums, sums_are_totals, rank, world, window, flags, random)
 
     def kld_insert(self, keys, n):
         k = keys.numpy()
@@ -111,10 +155,25 @@ class OracleShardBackend:
         return torch.from_numpy(k.astype(np.int64))
 
     def draw_window(self, rng, m0, m1, sums, sums_are_totals, rank, world, window, flags):
-        rs = [lcg_skip(rng, 2 * m + 2) / float(1 << 48) for m in range(m0, m1)]
-        self._fill_window(rs, m0, sums, sums_are_totals, rank, world, window, flags)
+        random = {}
+        if self._chain is not None:
+            rs = []
+            for m in range(m0, m1):
+                q, rnd = self._chain[m]
+                if rnd:
+                    random[m] = lcg_skip(rng, q)
+                    rs.append(None)
+                else:
+                    rs.append(lcg_skip(rng, q + 1) / float(1 << 48))
+        else:
+            rs = [lcg_skip(rng, 2 * m + 2) / float(1 << 48) for m in range(m0, m1)]
+        self._fill_window(rs, m0, sums, sums_are_totals, rank, world, window, flags, random)
 
-    def _fill_window(self, rs, m0, sums, sums_are_totals, rank, world, window, flags):
+    _chain = None
+    _n_random = 0
+    _w_diff = 0.0
+
+    def _fill_window(self, rs, m0, sums, sums_are_totals, rank, world, window, flags, random=None):
         m1 = m0 + len(rs)
         s = sums.tolist()
         if sums_are_totals:
@@ -131,6 +190,15 @@ class OracleShardBackend:
         n = self.samples.shape[0]
         cell_th = 10 * np.pi / 180
         for m in range(m0, m1):
+            o = m - m0
+            if random and m in random:
+                if rank == 0:  # the random free-space poses are written by shard 0 only
+                    p = self._random_pose(random[m])
+                    w[0:3, o] = p.view(np.int64)
+                    w[3, o] = int(np.floor(p[0] / 0.5))
+                    w[4, o] = int(np.floor(p[1] / 0.5))
+                    w[5, o] = int(np.floor(p[2] / cell_th))
+                continue
             r = rs[m - m0]
             mine = r >= offset and (r < top or rank == world - 1)
             if not mine:

@@ -266,3 +266,82 @@ def test_two_ranks_prob_model_with_beam_skipping(tmp_path):
         merged = np.concatenate([r0["samples"], r1["samples"]])
         assert np.array_equal(merged[:, :3], pf.getCurrentSet().samples[:, :3])
     e.close()
+
+
+RECOVERY_ALPHA = (0.001, 0.1)  # the node's default decay rates (node.cpp:122-123)
+
+
+def _recovery_scan(sc, cycle):
+    return [sc.ranges, np.clip(sc.ranges * 0.6, 0.05, 29.0), np.full(sc.ranges.shape[0], 1.0)][cycle]
+
+
+def _recovery_worker(rank, world, port, out_dir, resampler):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+    from scenario import Scenario
+    orc, sc = _scenario("mixture")
+    n = sc.samples.shape[0]
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    e = bpf.Engine(0)
+    shard = Scenario.__new__(Scenario)
+    shard.__dict__.update(sc.__dict__)
+    shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
+    m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21, alpha=RECOVERY_ALPHA)
+    pf.setResampleModel(resampler)
+    pf.setRandomPoseGenerator(hpf.RANDOM_POSE_FREE_SPACE_2D)
+    sf = ShardedFilter(HipShardBackend(e, scn, pf, torch.device("cuda", 0)), dist, first_window=1024)
+    recs = []
+    for cycle in range(3):
+        sf.update_sensor(bpf.PlanarData(_recovery_scan(sc, cycle), sc.angles, sc.range_max))
+        sf.update_resample()
+        st = sf.state()
+        recs.append(dict(samples=pf.getCurrentSet().samples.copy(), M=st.sample_count, leaf=st.leaf_count,
+                         rng=pf.getRngState(), w_slow=st.w_slow))
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(recs, dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    e.close()
+
+
+@pytest.mark.parametrize("resampler", [0, 1])
+def test_two_ranks_recovery_random_poses(tmp_path, resampler):
+    """w_diff > 0 over shards: every rank resolves the same draw chain, shard 0 contributes the random free-space
+    poses, the averages are reset on every shard; equal to the single engine (itself checked against the oracle
+    in test_gpu_parity.py::test_recovery_random_poses_match_oracle)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_recovery_worker, args=(2, port, str(tmp_path), resampler), nprocs=2, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    orc, sc = _scenario("mixture")
+    n = sc.samples.shape[0]
+    e = bpf.Engine(0)
+    m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21, alpha=RECOVERY_ALPHA)
+    pf.setResampleModel(resampler)
+    pf.setRandomPoseGenerator(hpf.RANDOM_POSE_FREE_SPACE_2D)
+    w_diffs = []
+    for cycle in range(3):
+        scn.updateSensor(pf, bpf.PlanarData(_recovery_scan(sc, cycle), sc.angles, sc.range_max))
+        pf.updateResample()
+        st = pf.getState()
+        w_diffs.append(st.w_diff)
+        cur = pf.getCurrentSet().samples
+        r0, r1 = recs[0][cycle], recs[1][cycle]
+        for r in (r0, r1):
+            assert r["M"] == st.sample_count and r["leaf"] == st.leaf_count and r["rng"] == pf.getRngState()
+            assert r["w_slow"] == st.w_slow
+        merged = np.concatenate([r0["samples"], r1["samples"]])
+        assert np.array_equal(merged[:, :3], cur[:, :3])
+    assert max(w_diffs) > 0.01
+    e.close()

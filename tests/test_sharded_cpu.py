@@ -18,6 +18,14 @@ ODOM = (2, (0.05, 0.04, 0.03, 0.02, 0.0))                       # diff-corrected
 ODATA = ((1.0, 2.0, 0.3), (0.03, -0.01, 0.02), (0.03, 0.01, 0.02))  # pose, delta, absolute motion
 
 
+RECOVERY_ALPHA = (0.001, 0.1)  # the node's default decay rates (node.cpp:122-123)
+
+
+def _scan(sc, cycle):
+    """Scan 0 fits the map; scans 1 and 2 are progressively worse, so w_fast falls below w_slow."""
+    return [sc.ranges, np.clip(sc.ranges * 0.6, 0.05, 29.0), np.full(sc.ranges.shape[0], 1.0)][cycle]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -32,7 +40,7 @@ def _scenario():
     return orc, Scenario(orc, size=200, n=1200, beams=61, cloud="mixture")
 
 
-def _worker(rank, world, port, out_dir, cloud_split, resampler):
+def _worker(rank, world, port, out_dir, cloud_split, resampler, recovery):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -44,12 +52,15 @@ def _worker(rank, world, port, out_dir, cloud_split, resampler):
     n = sc.samples.shape[0]
     lo, hi = cloud_split[rank], cloud_split[rank + 1]
     planar = sc.oracle_planar(61, "lf")
-    b = OracleShardBackend(orc, sc.omap, planar, sc.samples[lo:hi], 100, n, seed=9)
+    b = OracleShardBackend(orc, sc.omap, planar, sc.samples[lo:hi], 100, n, seed=9,
+                           alpha=RECOVERY_ALPHA if recovery else (0.0, 0.0))
     b._resample_model = resampler
+    if recovery:
+        b.pfh.set_random_pose_source(sc.omap, sc.map_factors[2])
     sf = ShardedFilter(b, dist, first_window=256)
-    data = (sc.ranges, sc.angles, sc.range_max)
     records = []
-    for cycle in range(2):
+    for cycle in range(3 if recovery else 2):
+        data = (_scan(sc, cycle) if recovery else sc.ranges, sc.angles, sc.range_max)
         sf.update_action(ODOM, ODATA)
         sf.update_sensor(data)
         w_after = b.samples.copy()
@@ -63,24 +74,35 @@ def _worker(rank, world, port, out_dir, cloud_split, resampler):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("split,resampler", [((0, 600, 1200), 0), ((0, 137, 1200), 0), ((0, 500, 1200), 1)])
-def test_two_shards_equal_one_filter(tmp_path, split, resampler):
+@pytest.mark.parametrize("split,resampler,recovery", [((0, 600, 1200), 0, False), ((0, 137, 1200), 0, False),
+                                                      ((0, 500, 1200), 1, False), ((0, 700, 1200), 0, True),
+                                                      ((0, 300, 1200), 1, True)])
+def test_two_shards_equal_one_filter(tmp_path, split, resampler, recovery):
+    """recovery: the node's default decay rates and a worsening scan, so that w_diff > 0 and both resamplers
+    mix in random free-space poses (every rank resolves the same draw chain, shard 0 writes the random poses)."""
     sys.path.insert(0, HERE)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), split, resampler), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), split, resampler, recovery), nprocs=2, join=True)
     recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
 
     orc, sc = _scenario()
     n = sc.samples.shape[0]
-    opf = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0, seed=9)
+    a = RECOVERY_ALPHA if recovery else (0.0, 0.0)
+    opf = orc.ParticleFilter(100, n, a[0], a[1], 85.0, seed=9)
     opf.set_samples(sc.samples)
     opf.set_resample_model(resampler)
+    if recovery:
+        opf.set_random_pose_source(sc.omap, sc.map_factors[2])
     p = sc.oracle_planar(61, "lf")
-    for cycle in range(2):
+    w_diffs = []
+    for cycle in range(3 if recovery else 2):
         opf.pf.rng = orc.odom_update_action(ODOM[0], ODOM[1], *ODATA, opf.samples[:opf.sample_count], opf.pf.rng)
-        opf.update_sensor(lambda s, conv: sc.oracle_apply(p, s, conv))
+        ranges = _scan(sc, cycle) if recovery else sc.ranges
+        opf.update_sensor(lambda s, conv: orc.planar_apply(p, sc.omap, s, ranges, sc.angles, sc.range_max, conv))
         w_ref = opf.samples[:opf.sample_count, 3].copy()
         out = opf.update_resample()
+        w_diffs.append(out.w_diff)
+        assert out.status == 0
         r0, r1 = recs[0][cycle], recs[1][cycle]
         # normalised weights: rank-ordered total vs the serial total differ by rounding only
         w_sh = np.concatenate([r0["w"][:, 3], r1["w"][:, 3]])
@@ -90,7 +112,7 @@ def test_two_shards_equal_one_filter(tmp_path, split, resampler):
             assert r["leaf"] == out.leaf_count and r["bins"] == out.node_count
             assert r["rng"] == opf.pf.rng
             assert r["conv"] == out.converged
-            assert abs(r["w_slow"] - opf.pf.w_slow) <= 1e-12 * opf.pf.w_slow
+            assert abs(r["w_slow"] - opf.pf.w_slow) <= 1e-12 * opf.pf.w_slow + 0.0
         M = out.sample_count
         merged = np.concatenate([r0["samples"], r1["samples"]])
         assert merged.shape[0] == M
@@ -98,5 +120,7 @@ def test_two_shards_equal_one_filter(tmp_path, split, resampler):
         assert np.all(merged[:, 3] == 1.0 / M)
         # shards are the even, index-ordered split
         assert r0["samples"].shape[0] == M // 2 and r1["samples"].shape[0] == M - M // 2
+    if recovery:
+        assert max(w_diffs) > 0.01  # the recovery branch really ran
     if resampler == 0:
         assert recs[0][0]["windows"] >= 2  # first_window=256 forces the multi-window path
