@@ -68,6 +68,8 @@ SIGNATURES = {
     "bpf_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "bpf_get_cells_walked": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
     "bpf_pf_get_state": (C.c_int, [_vp, C.POINTER(PFState)]),
+    "bpf_pf_init_with_gaussian": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "bpf_pf_init_with_random_poses": (C.c_int, [_vp]),
     "bpf_odom_set_model": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "bpf_pf_update_action": (C.c_int, [_vp, _dp, _dp, _dp]),
     "bpf_shard_update_action": (C.c_int, [_vp, _dp, _dp, _dp, C.c_longlong, C.c_longlong]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <queue>
 #include <cmath>
 #include <chrono>
@@ -288,7 +289,7 @@ struct bpf_engine
   bool odom_configured = false;
   DevBuf<int> d_motion_counts;
   DevBuf<long long> d_motion_offsets, d_motion_result;
-  DevBuf<double> d_gauss;
+  DevBuf<double> d_gauss, d_init_rot;
   PinnedBuf<long long> h_motion_result;
 
   // ---- cluster statistics (host, lazy)
@@ -1154,7 +1155,8 @@ int build_draw_chain(bpf_engine* e, double w_diff, int max_draws)
 // Returns BPF_OK with *stop_out = stop count (or -1: no stop), *leaf_out / *bins_out at the final count;
 // *handled = false when a key does not fit the 64-bit packing or the tree is deeper than the level budget
 // (the caller then replays on the host as before).
-int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out)
+int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out,
+                       bool whole_stream = false)
 {
   *handled = false;
   const int n = maxs;
@@ -1247,7 +1249,7 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpyAsync(e->h_kld.p, e->d_kld_flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  const int stop = e->h_kld.p[2];
+  const int stop = whole_stream ? -1 : e->h_kld.p[2];  // whole_stream: the tree of all n keys, no stop rule
   const int M = (stop >= 1 && stop <= n) ? stop : n;
   int2 c;
   HIPCHK(e, hipMemcpyAsync(&c, e->d_kld_counts.p + (M - 1), sizeof(int2), hipMemcpyDeviceToHost, e->stream));
@@ -2323,22 +2325,17 @@ MotionModelDev motion_constants(const bpf_engine* e, const double pose[3], const
   return M;
 }
 
-int update_action(bpf_engine* e, const double pose[3], const double delta[3], const double absolute_motion[3],
-                  long long global_first, long long global_count)
+// `need` Gaussians PDFGaussian::draw(sd[rank % 3]) from the filter's drand48 stream, ranks
+// [first, first + count) materialised in d_gauss; *consumed_out = uniforms the whole update took.
+// `after_gauss` is launched right behind the generation (optimistically: a rare second pass re-runs it).
+int generate_gaussians(bpf_engine* e, long long need, long long first, long long count, const double sd[3],
+                       long long* consumed_out, const std::function<void()>& after_gauss)
 {
-  const int n = e->sample_count;
-  if (global_first < 0 || global_first + n > global_count)
-    return e->fail(BPF_ERR_INVALID_ARGUMENT, "shard range outside the global set");
-  HIPCHK(e, hipSetDevice(e->device));
-  const MotionModelDev M = motion_constants(e, pose, delta, absolute_motion);
-  const long long need = 3 * global_count;
   // attempts are accepted with probability pi/4; 6 sigma of slack, doubled on the (never yet seen) shortfall
   long long attempts = (long long)std::ceil((double)need / 0.7853981633974483 + 6.0 * std::sqrt((double)need)) + 64;
   HIPCHK(e, e->d_motion_result.reserve(4));
   HIPCHK(e, e->h_motion_result.reserve(4));
-  HIPCHK(e, e->d_gauss.reserve((size_t)3 * n));
-  SampleSet& src = e->sets[e->cur];
-  SampleSet& dst = e->sets[e->cur ^ 1];
+  HIPCHK(e, e->d_gauss.reserve((size_t)std::max<long long>(count, 1)));
   long long zero_at = kNoZero;
   for (int round = 0; round < 8; ++round)
   {
@@ -2350,14 +2347,14 @@ int update_action(bpf_engine* e, const double pose[3], const double delta[3], co
     A.zero_at = zero_at;
     A.n_attempts = attempts;
     A.need_total = need;
-    A.gauss_first = 3 * global_first;
-    A.gauss_count = 3ll * n;
+    A.gauss_first = first;
+    A.gauss_count = count;
     A.tile_counts = e->d_motion_counts.p;
     A.tile_offsets = e->d_motion_offsets.p;
     A.gauss = e->d_gauss.p;
     A.result = e->d_motion_result.p;
     for (int k = 0; k < 3; ++k)
-      A.sd[k] = M.sd[k];
+      A.sd[k] = sd[k];
     A.jump = e->jump;
     {
       ProfScope ps(e, BPF_K_MOTION);
@@ -2365,9 +2362,7 @@ int update_action(bpf_engine* e, const double pose[3], const double delta[3], co
       hipLaunchKernelGGL(k_motion_count, dim3(tiles), dim3(256), 0, e->stream, A);
       hipLaunchKernelGGL(k_motion_offsets, dim3(1), dim3(1024), 0, e->stream, A, tiles);
       hipLaunchKernelGGL(k_motion_gauss, dim3(tiles), dim3(256), 0, e->stream, A);
-      // optimistic: poses go to the other set, which becomes current only once the pass is known good
-      hipLaunchKernelGGL(k_motion_apply, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, src.dev(), dst.dev(), n,
-                         M, (const double*)e->d_gauss.p);
+      after_gauss();
       HIPCHK(e, hipGetLastError());
     }
     HIPCHK(e, hipMemcpyAsync(e->h_motion_result.p, e->d_motion_result.p, 4 * sizeof(long long), hipMemcpyDeviceToHost,
@@ -2385,15 +2380,78 @@ int update_action(bpf_engine* e, const double pose[3], const double delta[3], co
       attempts *= 2;
       continue;
     }
-    e->rng = lcg_skip_host(e->rng, (uint64_t)consumed, e->jump);
-    e->cur ^= 1;
-    e->tile_sums_n = -1;
-    e->fused_partials = 0;
-    e->set_epoch++;
-    e->hist_matches_set = false;
+    *consumed_out = consumed;
     return BPF_OK;
   }
-  return e->fail(BPF_ERR_HIP, "motion update: Gaussian stream did not fill (internal error)");
+  return e->fail(BPF_ERR_HIP, "Gaussian stream did not fill (internal error)");
+}
+
+int update_action(bpf_engine* e, const double pose[3], const double delta[3], const double absolute_motion[3],
+                  long long global_first, long long global_count)
+{
+  const int n = e->sample_count;
+  if (global_first < 0 || global_first + n > global_count)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "shard range outside the global set");
+  HIPCHK(e, hipSetDevice(e->device));
+  const MotionModelDev M = motion_constants(e, pose, delta, absolute_motion);
+  SampleSet& src = e->sets[e->cur];
+  SampleSet& dst = e->sets[e->cur ^ 1];
+  long long consumed = 0;
+  // optimistic: poses go to the other set, which becomes current only once the pass is known good
+  int rc = generate_gaussians(e, 3 * global_count, 3 * global_first, 3ll * n, M.sd, &consumed, [&]() {
+    hipLaunchKernelGGL(k_motion_apply, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, src.dev(), dst.dev(), n, M,
+                       (const double*)e->d_gauss.p);
+  });
+  if (rc != BPF_OK)
+    return rc;
+  e->rng = lcg_skip_host(e->rng, (uint64_t)consumed, e->jump);
+  e->cur ^= 1;
+  e->tile_sums_n = -1;
+  e->fused_partials = 0;
+  e->set_epoch++;
+  e->hist_matches_set = false;
+  return BPF_OK;
+}
+
+// what initWithGaussian / initWithPoseFn leave besides the poses (particle_filter.cpp:126-131,157-162): the
+// histogram tree of the set (leaf / bin counts), w_slow = w_fast = 0, converged = false
+int finish_init(bpf_engine* e, int n)
+{
+  SampleSet& s = e->sets[e->cur];
+  e->sample_count = n;
+  e->tile_sums_n = -1;
+  e->fused_partials = 0;
+  e->set_epoch++;
+  e->hist_matches_set = false;
+  HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
+  e->converged = 0;
+  e->converged_pending = false;
+  HIPCHK(e, e->d_keys.reserve((size_t)n * 3));
+  hipLaunchKernelGGL(k_set_keys, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.dev(), n, e->d_keys.p);
+  HIPCHK(e, hipGetLastError());
+  bool handled = false;
+  int stop = -1, leaf = 0, bins = 0;
+  if (n >= 8192)
+  {
+    int rc = kld_tree_on_device(e, n, &handled, &stop, &leaf, &bins, true);
+    if (rc != BPF_OK)
+      return rc;
+  }
+  if (!handled)
+  {
+    std::vector<int> keys((size_t)n * 3);
+    HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_keys.p, keys.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->hist.clear();
+    for (int i = 0; i < n; ++i)
+      e->hist.insert(keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2]);
+    leaf = e->hist.leaf_count();
+    bins = e->hist.bin_count();
+    e->hist_matches_set = true;
+  }
+  e->leaf_count = leaf;
+  e->bin_count = bins;
+  return BPF_OK;
 }
 }  // namespace
 
@@ -2412,6 +2470,49 @@ int bpf_odom_set_model(bpf_engine* e, int model_type, double alpha1, double alph
   e->odom_alpha[4] = alpha5;
   e->odom_configured = true;
   return BPF_OK;
+}
+
+int bpf_pf_init_with_gaussian(bpf_engine* e, const double mean[3], const double rotation[9], const double sigma[3])
+{
+  if (!e || !mean || !rotation || !sigma)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  const int n = e->max_samples;
+  HIPCHK(e, e->d_init_rot.reserve(9));
+  HIPCHK(e, hipMemcpyAsync(e->d_init_rot.p, rotation, 9 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // `rotation` is the caller's memory
+  SampleSet& dst = e->sets[e->cur];
+  long long consumed = 0;
+  int rc = generate_gaussians(e, 3ll * n, 0, 3ll * n, sigma, &consumed, [&]() {
+    hipLaunchKernelGGL(k_init_gaussian, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, dst.dev(), n,
+                       (const double*)e->d_gauss.p, mean[0], mean[1], mean[2], (const double*)e->d_init_rot.p,
+                       1.0 / (double)n);
+  });
+  if (rc != BPF_OK)
+    return rc;
+  e->rng = lcg_skip_host(e->rng, (uint64_t)consumed, e->jump);
+  return finish_init(e, n);
+}
+
+int bpf_pf_init_with_random_poses(bpf_engine* e)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  HIPCHK(e, hipSetDevice(e->device));
+  FreeSpaceDev fs{};
+  int rc = ensure_free_space(e, &fs);
+  if (rc != BPF_OK)
+    return rc;
+  const int n = e->max_samples;
+  hipLaunchKernelGGL(k_init_free_space, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->sets[e->cur].dev(), n,
+                     e->rng, e->jump, fs, 1.0 / (double)n);
+  HIPCHK(e, hipGetLastError());
+  e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)n, e->jump);
+  return finish_init(e, n);
 }
 
 int bpf_pf_update_action(bpf_engine* e, const double pose[3], const double delta[3], const double absolute_motion[3])

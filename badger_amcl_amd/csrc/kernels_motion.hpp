@@ -242,4 +242,55 @@ __global__ void k_motion_apply(const ParticlesDev src, const ParticlesDev dst, i
   dst.w[i] = src.w[i];
 }
 
+// ParticleFilter::initWithGaussian (particle_filter.cpp:105-132): pose = x + cr * r, r[k] = draw(cd[k]) -- the
+// sum over j is formed term by term as PDFGaussian::sample does (pdf_gaussian.cpp:63-68)
+__global__ void k_init_gaussian(ParticlesDev dst, int n, const double* __restrict__ gauss, double mx, double my,
+                                double mth, const double* __restrict__ cr9, double weight)
+{
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const double r[3] = { gauss[3 * (size_t)i], gauss[3 * (size_t)i + 1], gauss[3 * (size_t)i + 2] };
+  const double m[3] = { mx, my, mth };
+  double v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+  {
+    v[k] = m[k];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      v[k] += cr9[3 * k + j] * r[j];
+  }
+  dst.x[i] = v[0];
+  dst.y[i] = v[1];
+  dst.th[i] = v[2];
+  dst.w[i] = weight;
+}
+
+// ParticleFilter::initWithPoseFn (particle_filter.cpp:135-163) with pose_fn = Node::randomFreeSpacePose:
+// sample i takes stream elements 2i+1, 2i+2
+__global__ void k_init_free_space(ParticlesDev dst, int n, uint64_t rng_state, LcgJump jump, FreeSpaceDev F,
+                                  double weight)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const uint64_t xs = lcg_skip(rng_state, 2ull * (uint64_t)i + 1ull, jump);
+  double x, y, th;
+  random_free_space_pose(F, ldexp((double)xs, -48), ldexp((double)lcg_next(xs), -48), &x, &y, &th);
+  dst.x[i] = x;
+  dst.y[i] = y;
+  dst.th[i] = th;
+  dst.w[i] = weight;
+}
+
+// histogram keys of a set (AoS triples), for the tree of a freshly initialised set
+__global__ void k_set_keys(ParticlesDev p, int n, int* __restrict__ keys)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    pose_key(p.x[i], p.y[i], p.th[i], &keys[3 * (size_t)i]);
+}
+
 }  // namespace bpf

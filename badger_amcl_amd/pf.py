@@ -244,6 +244,16 @@ class ParticleFilter:
         assert s.ndim == 2 and s.shape[1] == 4
         self.e.check(self.e.lib.bpf_pf_set_samples(self.e.h, _dp(s), s.shape[0], leaf_count))
 
+    def initWithGaussian(self, mean, rotation, sigma):
+        """ParticleFilter::initWithGaussian given PDFGaussian's decomposition (cr_ row-major 3x3, cd_)."""
+        m, r, d = (np.ascontiguousarray(v, dtype=np.float64).reshape(-1) for v in (mean, rotation, sigma))
+        assert m.size == 3 and r.size == 9 and d.size == 3
+        self.e.check(self.e.lib.bpf_pf_init_with_gaussian(self.e.h, _dp(m), _dp(r), _dp(d)))
+
+    def initWithRandomPoses(self):
+        """ParticleFilter::initWithPoseFn with the generator of setRandomPoseGenerator (global localisation)."""
+        self.e.check(self.e.lib.bpf_pf_init_with_random_poses(self.e.h))
+
     def initWithPoseFn(self, pose_fn):
         s = np.zeros((self.max_samples, 4), dtype=np.float64)
         for i in range(self.max_samples):

@@ -230,6 +230,16 @@ int bpf_pf_update_action(bpf_engine* e, const double pose[3], const double delta
 int bpf_shard_update_action(bpf_engine* e, const double pose[3], const double delta[3],
                             const double absolute_motion[3], long long global_first, long long global_count);
 
+/* Initialisers on the resident set, drawing from the filter's drand48 stream like the reference:
+ * ParticleFilter::initWithGaussian (particle_filter.cpp:105-132) given what PDFGaussian's constructor derives from
+ * the covariance with Eigen::EigenSolver (third party; pdf_gaussian.cpp:32-46,100-131): `rotation` = cr_ (row-major
+ * 3x3), `sigma` = cd_ (square roots of the eigenvalues); every sample is mean + cr * (draw(cd0), draw(cd1), draw(cd2)).
+ * ParticleFilter::initWithPoseFn (:135-163) with the generator set by bpf_pf_set_random_pose_generator (global
+ * localisation, node.cpp:870-882).  Both fill max_samples particles with weight 1/max_samples, build the set's
+ * histogram tree (leaf count), zero w_slow / w_fast and clear the converged flag. */
+int bpf_pf_init_with_gaussian(bpf_engine* e, const double mean[3], const double rotation[9], const double sigma[3]);
+int bpf_pf_init_with_random_poses(bpf_engine* e);
+
 /* ------------------------------------------------------------------ cluster statistics
  * ParticleFilter::computeClusterStatsForSet (particle_filter.cpp:505-636) with PFKDTree::cluster
  * (pf_kdtree.cpp:58-90,169-194), and what Node2D::getMaxWeightPose (node_2d.cpp:588-617) reads.

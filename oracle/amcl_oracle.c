@@ -1108,6 +1108,56 @@ void orc_random_free_space_pose(const orc_free_space* fs, uint64_t* rng, double 
   pose[2] = orc_drand48(rng) * 2 * M_PI - M_PI;
 }
 
+/* particle_filter.cpp:135-163 */
+int orc_pf_init_with_free_space_poses(orc_pf* pf, const orc_free_space* fs, double* samples, int n, int* node_count)
+{
+  orc_kdtree* tree = orc_kdtree_new();
+  for (int i = 0; i < n; i++)
+  {
+    double* s = &samples[4 * i];
+    s[3] = 1.0 / pf->max_samples;
+    orc_random_free_space_pose(fs, &pf->rng, s);
+    orc_kdtree_insert(tree, s, s[3]);
+  }
+  pf->w_slow = pf->w_fast = 0.0;
+  pf->converged = 0;
+  const int leaf = orc_kdtree_leaf_count(tree);
+  if (node_count)
+    *node_count = orc_kdtree_node_count(tree);
+  orc_kdtree_free(tree);
+  return leaf;
+}
+
+/* particle_filter.cpp:105-132 + pdf_gaussian.cpp:52-70 */
+int orc_pf_init_with_gaussian(orc_pf* pf, const double mean[3], const double cr[9], const double cd[3],
+                              double* samples, int n, int* node_count)
+{
+  orc_kdtree* tree = orc_kdtree_new();
+  for (int i = 0; i < n; i++)
+  {
+    double* s = &samples[4 * i];
+    s[3] = 1.0 / pf->max_samples;
+    double r[3];
+    for (int k = 0; k < 3; k++)
+      r[k] = orc_gaussian_draw(&pf->rng, cd[k]);
+    for (int k = 0; k < 3; k++)
+    {
+      double v = mean[k];
+      for (int j = 0; j < 3; j++)
+        v += cr[3 * k + j] * r[j];
+      s[k] = v;
+    }
+    orc_kdtree_insert(tree, s, s[3]);
+  }
+  pf->w_slow = pf->w_fast = 0.0;
+  pf->converged = 0;
+  const int leaf = orc_kdtree_leaf_count(tree);
+  if (node_count)
+    *node_count = orc_kdtree_node_count(tree);
+  orc_kdtree_free(tree);
+  return leaf;
+}
+
 /* particle_filter.cpp:356-420 */
 static double resample_multinomial(orc_pf* pf, const double* a, int n_a, double w_diff, double* b, int* idx,
                                    orc_kdtree* tree, int* m_out, int* status)

@@ -141,6 +141,14 @@ typedef struct orc_free_space
   int size_x, size_y;
   double origin_x, origin_y, resolution;
 } orc_free_space;
+/* ParticleFilter::initWithPoseFn (particle_filter.cpp:135-163) with pose_fn = Node::randomFreeSpacePose, and
+ * ParticleFilter::initWithGaussian (:105-132) with PDFGaussian::sample (pdf_gaussian.cpp:52-70) given the
+ * decomposition the constructor obtains from Eigen::EigenSolver (third party): cr = rotation (row-major 3x3),
+ * cd = sqrt of the eigenvalues.  samples = [n][4] (n = max_samples); returns the kd-tree leaf count, node count
+ * in *node_count. */
+int orc_pf_init_with_free_space_poses(orc_pf* pf, const orc_free_space* fs, double* samples, int n, int* node_count);
+int orc_pf_init_with_gaussian(orc_pf* pf, const double mean[3], const double cr[9], const double cd[3],
+                              double* samples, int n, int* node_count);
 /* returns the number of free cells; ij_out (capacity pairs) may be NULL to count only */
 int orc_free_space_indices(const orc_map2d* m, double non_free_space_radius, int* ij_out, int capacity);
 /* Node::randomFreeSpacePose: two drand48 draws */

@@ -131,6 +131,8 @@ def lib():
     L.orc_pf_resample_limit.argtypes = [C.POINTER(PF), C.c_int]
     L.orc_pf_update_resample.argtypes = [C.POINTER(PF), dp, C.c_int, C.c_int, dp, ip, C.POINTER(ResampleOut)]
     L.orc_pf_update_converged.argtypes = [C.POINTER(PF), dp, C.c_int, C.POINTER(C.c_float)]
+    L.orc_pf_init_with_free_space_poses.argtypes = [C.POINTER(PF), C.POINTER(FreeSpace), dp, C.c_int, ip]
+    L.orc_pf_init_with_gaussian.argtypes = [C.POINTER(PF), dp, dp, dp, dp, C.c_int, ip]
     L.orc_free_space_indices.argtypes = [C.POINTER(Map2D), C.c_double, ip, C.c_int]
     L.orc_random_free_space_pose.argtypes = [C.POINTER(FreeSpace), C.POINTER(C.c_uint64), dp]
     L.orc_random_free_space_pose.restype = None
@@ -353,6 +355,24 @@ class ParticleFilter:
 
     def set_population_size_parameters(self, pop_err, pop_z):
         self.pf.pop_err, self.pf.pop_z = pop_err, pop_z
+
+    def init_with_free_space_poses(self):
+        """initWithPoseFn(Node::randomFreeSpacePose); needs set_random_pose_source."""
+        n = self.pf.max_samples
+        self.samples = np.zeros((n, 4), dtype=np.float64)
+        nodes = C.c_int()
+        self.leaf_count = lib().orc_pf_init_with_free_space_poses(C.byref(self.pf), C.byref(self._free),
+                                                                  _dp(self.samples), n, C.byref(nodes))
+        self.sample_count, self.node_count, self.set_converged = n, nodes.value, 0
+
+    def init_with_gaussian(self, mean, cr, cd):
+        n = self.pf.max_samples
+        self.samples = np.zeros((n, 4), dtype=np.float64)
+        nodes = C.c_int()
+        m, r, d = (np.ascontiguousarray(v, dtype=np.float64) for v in (mean, cr, cd))
+        self.leaf_count = lib().orc_pf_init_with_gaussian(C.byref(self.pf), _dp(m), _dp(r.reshape(-1)), _dp(d),
+                                                          _dp(self.samples), n, C.byref(nodes))
+        self.sample_count, self.node_count, self.set_converged = n, nodes.value, 0
 
     def set_random_pose_source(self, omap, non_free_space_radius):
         """random_pose_fn_ = Node::randomFreeSpacePose over Node2D::updateFreeSpaceIndices of `omap`."""

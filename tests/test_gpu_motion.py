@@ -136,3 +136,58 @@ def test_sharded_update_equals_whole(engine, orc):
         finally:
             e2.close()
     assert np.array_equal(np.concatenate(parts), whole)
+
+
+@pytest.mark.parametrize("n", [500, 20000])
+def test_init_with_gaussian_matches_oracle(engine, orc, n):
+    """ParticleFilter::initWithGaussian given PDFGaussian's decomposition: drand48 state and leaf / bin counts exact,
+    poses within POSE_TOL (device log), weights 1/max_samples, averages zeroed, not converged."""
+    import badger_amcl_amd as bpf
+    mean = (12.5, -3.25, 0.8)
+    ang = 0.4
+    cr = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+    cd = (0.5, 0.2, 0.1)
+    pf = bpf.ParticleFilter(engine, 10, n, 0.001, 0.1, 85.0)
+    pf.setRngState(0xABCDEF12330E)
+    pf.initWithGaussian(mean, cr, cd)
+    opf = orc.ParticleFilter(10, n, 0.001, 0.1, 85.0)
+    opf.pf.rng = 0xABCDEF12330E
+    opf.init_with_gaussian(mean, cr, cd)
+    st = pf.getState()
+    got = pf.getCurrentSet().samples
+    assert st.sample_count == n and pf.getRngState() == opf.pf.rng
+    assert np.abs(got[:, :3] - opf.samples[:, :3]).max() <= POSE_TOL
+    assert np.all(got[:, 3] == 1.0 / n)
+    assert st.w_slow == 0.0 and st.w_fast == 0.0 and st.converged == 0
+    # the tree is built from the DEVICE poses: compare with the oracle's tree on those (a pose within 1e-15 of
+    # a bin edge could differ from the oracle's own sample)
+    t = orc.KDTree()
+    for r in got[:, :3]:
+        t.insert_pose(r, 1.0)
+    assert (st.leaf_count, st.bin_count) == (t.leaf_count(), t.node_count())
+
+
+@pytest.mark.parametrize("n", [700, 30000])
+def test_init_with_random_free_space_poses_matches_oracle(engine, orc, n):
+    """ParticleFilter::initWithPoseFn(Node::randomFreeSpacePose) -- global localisation: everything exact."""
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    from scenario import Scenario
+    sc_ = Scenario(orc, size=200, n=64, beams=61)
+    m, sc, pf0, data = sc_.gpu_objects(engine, 61, "lf")
+    pf = bpf.ParticleFilter(engine, 10, n, 0.0, 0.0, 85.0)
+    pf.setRandomPoseGenerator(hpf.RANDOM_POSE_FREE_SPACE_2D)
+    pf.srand48(99)
+    pf.initWithRandomPoses()
+    opf = orc.ParticleFilter(10, n, 0.0, 0.0, 85.0, seed=99)
+    assert opf.set_random_pose_source(sc_.omap, sc_.map_factors[2]) > 1000
+    opf.init_with_free_space_poses()
+    st = pf.getState()
+    got = pf.getCurrentSet().samples
+    assert np.array_equal(got, opf.samples)
+    assert pf.getRngState() == opf.pf.rng
+    assert (st.sample_count, st.leaf_count, st.bin_count) == (n, opf.leaf_count, opf.node_count)
+    # and the filter works from there
+    sc.updateSensor(pf, data)
+    pf.updateResample()
+    assert 10 <= pf.getState().sample_count <= n
