@@ -122,6 +122,7 @@ SIGNATURES = {
     "bpf_kld_insert_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "bpf_kld_stop_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
     "bpf_kld_leaf_count": (C.c_int, [_vp, _ip, _ip]),
+    "bpf_device_memory_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "bpf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "bpf_profile_reset": (C.c_int, [_vp]),
     "bpf_profile_get": (C.c_int, [_vp, C.POINTER(Profile)]),

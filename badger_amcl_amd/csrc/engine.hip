@@ -35,11 +35,16 @@ constexpr int kMaxBeams = 4096;     // beams staged in LDS per launch
 constexpr int kTableLdsMax = 2048;  // table entries that still go to LDS
 constexpr int kEventPool = 8192;
 
+// Device / pinned buffers free themselves with the engine (bpf_destroy selects the device first).
 template <typename T>
 struct DevBuf
 {
   T* p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
   hipError_t reserve(size_t n)
   {
     if (n <= cap)
@@ -67,6 +72,10 @@ struct PinnedBuf
 {
   T* p = nullptr;
   size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { release(); }
   hipError_t reserve(size_t n)
   {
     if (n <= cap)
@@ -1602,17 +1611,7 @@ void bpf_destroy(bpf_engine* e)
     (void)hipEventDestroy(ev);
   for (auto ev : e->ev_stop)
     (void)hipEventDestroy(ev);
-  e->d_lut_tiles.release(); e->d_cheb.release(); e->d_cells8.release(); e->d_levels.release();
-  e->d_lut_f32.release(); e->d_edt_tmp.release(); e->d_obs_count.release();
-  e->d_cells_walked.release();
-  e->d_prep.release(); e->d_prep_stats.release(); e->d_chunk_partials.release(); e->d_plan.release();
-  e->d_pose_indices.release(); e->d_ratios.release(); e->d_affine.release(); e->d_points.release();
-  e->d_cloud_partials.release(); e->d_cloud_table.release(); e->h_points.release(); e->h_cloud_table.release();
-  e->sets[0].release(); e->sets[1].release(); e->scratch.release(); e->snap.release();
-  e->d_cdf.release(); e->d_partials.release(); e->d_targets.release(); e->d_scalars.release();
-  e->d_block_partials.release(); e->d_tile_sums.release();
-  e->d_keys.release(); e->d_src_index.release(); e->d_flags.release(); e->d_aos.release();
-  e->h_keys.release(); e->h_targets.release(); e->h_done.release(); e->h_flags.release(); e->h_scalars.release(); e->h_aos.release();
+  // every DevBuf / PinnedBuf member frees itself when the engine is deleted (the device is selected above)
   if (e->own_stream)
     (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -3866,6 +3865,15 @@ int bpf_get_cells_walked(bpf_engine* e, unsigned long long* out, int reset)
 }
 
 // ---------------------------------------------------------------------- measurement
+int bpf_device_memory_info(int device_ordinal, size_t* free_bytes, size_t* total_bytes)
+{
+  if (!free_bytes || !total_bytes)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess)
+    return BPF_ERR_HIP;
+  return BPF_OK;
+}
+
 int bpf_profile_enable(bpf_engine* e, int on)
 {
   if (!e)

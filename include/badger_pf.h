@@ -423,6 +423,8 @@ int bpf_wire_decimate_cloud(const float* points_xyz, int n_points, int max_beams
 int bpf_wire_samples_to_pose_array(const double* samples, int sample_count, double* poses7_out);
 
 /* ------------------------------------------------------------------ measurement */
+/* free / total device memory as hipMemGetInfo reports it (diagnostic; used by the leak test) */
+int bpf_device_memory_info(int device_ordinal, size_t* free_bytes, size_t* total_bytes);
 enum
 {
   BPF_K_SCORE = 0,     /* sensor scoring kernel, gather form (k_score_field / k_score_beam / k_cloud_score) */

@@ -166,3 +166,40 @@ def test_edge_cases_of_the_set(engine, world):
     pf.initWithSamples(z)
     sc.updateSensor(pf, data)
     assert np.all(pf.getCurrentSet().samples[:, 3] == 1.0 / 64)
+
+
+def test_engines_release_their_memory(orc):
+    """Create, use (every buffer family: motion, device tree, recovery chain, statistics) and destroy engines in a
+    loop: device memory does not creep."""
+    import ctypes as C
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    from badger_amcl_amd import _lib
+    from scenario import Scenario
+    sc_ = Scenario(orc, size=200, n=20000, beams=61, cloud="spread")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert _lib.load().bpf_device_memory_info(0, C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    def cycle():
+        e = bpf.Engine(0)
+        e.set_option(hpf.OPT_KLD_DEVICE_MIN, 1)
+        m, sc, pf, data = sc_.gpu_objects(e, 61, "lf", min_samples=100, seed=1, alpha=(0.001, 0.1))
+        pf.setRandomPoseGenerator(hpf.RANDOM_POSE_FREE_SPACE_2D)
+        od = bpf.Odom(e)
+        od.setModel(0, 0.1, 0.1, 0.1, 0.1)
+        for ranges in (sc_.ranges, np.full(61, 1.0)):
+            od.updateAction(pf, bpf.OdomData((0, 0, 0), (0.01, 0, 0.01)))
+            sc.updateSensor(pf, bpf.PlanarData(ranges, sc_.angles, sc_.range_max))
+            pf.updateResample()
+            pf.computeClusterStats()
+        e.close()
+
+    cycle()
+    free0 = free_bytes()
+    for _ in range(4):
+        cycle()
+    free1 = free_bytes()
+    assert free0 - free1 < 32 << 20, (free0, free1)
