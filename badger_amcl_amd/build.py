@@ -7,9 +7,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "engine.hip")
 OUT = os.path.join(HERE, "libbadger_pf_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("engine.hip", "device_types.hpp", "kernels_score.hpp", "kernels_pf.hpp", "kernels_cloud.hpp",
-         "kdhist.hpp")] + [os.path.join(os.path.dirname(HERE), "include", "badger_pf.h")]
+
+
+def deps():
+    """Every source the one translation unit pulls in: csrc/* and the C-ABI header."""
+    csrc = os.path.join(HERE, "csrc")
+    return [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))] + \
+        [os.path.join(os.path.dirname(HERE), "include", "badger_pf.h")]
 
 
 def hipcc():
@@ -23,7 +27,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force=False, verbose=False):

@@ -1,0 +1,385 @@
+// C-ABI: 3-D map + point cloud.
+// ---------------------------------------------------------------------- 3-D map + point cloud
+int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_indices, const uint8_t* distance_ratios,
+                  size_t n_distance_ratios, const int min_cells[3], const int max_cells[3], double resolution,
+                  double max_dist)
+{
+  if (!e || !pose_indices || !distance_ratios || !min_cells || !max_cells || !(resolution > 0) || !(max_dist > 0))
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad 3-D map arguments") : BPF_ERR_INVALID_ARGUMENT;
+  const long long w = (long long)max_cells[0] - min_cells[0] + 1, h = (long long)max_cells[1] - min_cells[1] + 1,
+                  nz = (long long)max_cells[2] - min_cells[2] + 1;
+  if (w <= 0 || h <= 0 || nz <= 0 || (size_t)(w * h) != n_pose_indices)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "pose_indices size does not match the cell bounds");
+  // every column start must leave room for a whole z column (octomap.cpp:315-333)
+  for (size_t i = 0; i < n_pose_indices; ++i)
+    if ((size_t)pose_indices[i] + (size_t)nz > n_distance_ratios)
+      return e->fail(BPF_ERR_INVALID_ARGUMENT, "pose_indices entry points past distance_ratios");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, e->d_pose_indices.reserve(n_pose_indices));
+  HIPCHK(e, e->d_ratios.reserve(n_distance_ratios));
+  HIPCHK(e, hipMemcpy(e->d_pose_indices.p, pose_indices, n_pose_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(e->d_ratios.p, distance_ratios, n_distance_ratios, hipMemcpyHostToDevice));
+  Map3dDev& M = e->map3;
+  M.pose_indices = e->d_pose_indices.p;
+  M.distance_ratios = e->d_ratios.p;
+  for (int d = 0; d < 3; ++d)
+  {
+    M.min_c[d] = min_cells[d];
+    M.max_c[d] = max_cells[d];
+  }
+  M.width = (int)w;
+  M.resolution = resolution;
+  M.inv_resolution = 1.0 / resolution;
+  e->map3_max_dist = max_dist;
+  e->n_pose_indices = n_pose_indices;
+  e->n_ratios = n_distance_ratios;
+  e->have_map3d = true;
+  return BPF_OK;
+}
+
+int bpf_map3d_build_distances_lut(bpf_engine* e, const int* occupied_ijk, size_t n_occupied, const int min_cells[3],
+                                  const int max_cells[3], double resolution, double max_dist)
+{
+  if (!e || (!occupied_ijk && n_occupied) || !min_cells || !max_cells || !(resolution > 0))
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad 3-D map arguments") : BPF_ERR_INVALID_ARGUMENT;
+  if (max_dist == 0.0)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "max distance to object is 0 (octomap.cpp:177-181)");
+  const long long w = (long long)max_cells[0] - min_cells[0] + 1, h = (long long)max_cells[1] - min_cells[1] + 1,
+                  nz = (long long)max_cells[2] - min_cells[2] + 1;
+  if (w <= 0 || h <= 0 || nz <= 0 || w * h > 0x7fffffffll)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "bad cell bounds");
+  struct Cell
+  {
+    int i, j, k, si, sj, sk;
+  };
+  struct Index3
+  {
+    int v[3];
+    bool operator<(const Index3& o) const  // octomap.h:51-54
+    {
+      return v[0] != o.v[0] ? v[0] < o.v[0] : v[1] != o.v[1] ? v[1] < o.v[1] : v[2] < o.v[2];
+    }
+  };
+  std::vector<uint32_t> pose_indices((size_t)(w * h), 0u);
+  std::vector<uint8_t> ratios((size_t)nz, 255);  // the shared all-255 column 0 (octomap.cpp:189-190)
+  const double ratio_unit = max_dist / 255;      // max_distance_ratio_ (octomap.cpp:57)
+  auto column = [&](int i, int j) { return (size_t)(j - min_cells[1]) * (size_t)w + (size_t)(i - min_cells[0]); };
+  auto get = [&](int i, int j, int k) {  // getDistanceToObject :336-350
+    return ratios[(size_t)pose_indices[column(i, j)] + (size_t)(k - min_cells[2])] * ratio_unit;
+  };
+  bool too_big = false;
+  auto set = [&](int i, int j, int k, double d) {  // setDistanceToObject :314-333
+    uint32_t& start = pose_indices[column(i, j)];
+    if (start == 0)
+    {
+      if (ratios.size() + (size_t)nz > 0xffffffffull)
+      {
+        too_big = true;
+        return;
+      }
+      start = (uint32_t)ratios.size();
+      ratios.resize(ratios.size() + (size_t)nz, 255);
+    }
+    d = std::min(d, max_dist);
+    d = d / max_dist * 255;
+    ratios[(size_t)start + (size_t)(k - min_cells[2])] = (uint8_t)static_cast<int>(std::floor(d));
+  };
+  // CachedDistanceOctoMap (:152-172)
+  const int radius = static_cast<int>(std::floor(max_dist / resolution));
+  const int td = radius + 2;
+  std::vector<double> cached((size_t)td * td * td);
+  for (int a = 0; a < td; ++a)
+    for (int b = 0; b < td; ++b)
+      for (int c = 0; c < td; ++c)
+        cached[((size_t)a * td + b) * td + c] = std::sqrt((double)(a * a + b * b + c * c)) * resolution;
+  // iterateObstacleCells (:208-249): zero distance in iteration order, FIFO seeded in descending Index3 order
+  std::priority_queue<Index3> ordering;
+  for (size_t q = 0; q < n_occupied; ++q)
+  {
+    const int* v = &occupied_ijk[3 * q];
+    bool valid = true;
+    for (int d = 0; d < 3; ++d)
+      valid = valid && v[d] >= min_cells[d] && v[d] <= max_cells[d];
+    if (!valid)
+      continue;
+    set(v[0], v[1], v[2], 0.0);
+    ordering.push(Index3{ { v[0], v[1], v[2] } });
+  }
+  std::queue<Cell> fifo;
+  while (!ordering.empty())
+  {
+    const Index3 s = ordering.top();
+    ordering.pop();
+    fifo.push(Cell{ s.v[0], s.v[1], s.v[2], s.v[0], s.v[1], s.v[2] });
+  }
+  // iterateEmptyCells / enqueue (:251-311)
+  static const int kShifts[6][3] = { { -1, 0, 0 }, { 0, -1, 0 }, { 0, 0, -1 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+  while (!fifo.empty() && !too_big)
+  {
+    const Cell cur = fifo.front();
+    const bool open[6] = { cur.i > min_cells[0], cur.j > min_cells[1], cur.k > min_cells[2],
+                           cur.i < max_cells[0], cur.j < max_cells[1], cur.k < max_cells[2] };
+    for (int s = 0; s < 6; ++s)
+    {
+      if (!open[s])
+        continue;
+      const int i = cur.i + kShifts[s][0], j = cur.j + kShifts[s][1], k = cur.k + kShifts[s][2];
+      const int di = std::abs(i - cur.si), dj = std::abs(j - cur.sj), dk = std::abs(k - cur.sk);
+      if (di >= td || dj >= td || dk >= td)
+        continue;  // the reference indexes its table unchecked; a cell this far out was never improved on the way
+      const double new_distance = cached[((size_t)di * td + dj) * td + dk];
+      const double old_distance = get(i, j, k);
+      if (old_distance - new_distance > ratio_unit)
+      {
+        set(i, j, k, new_distance);
+        fifo.push(Cell{ i, j, k, cur.si, cur.sj, cur.sk });
+      }
+    }
+    fifo.pop();
+  }
+  if (too_big)
+    return e->fail(BPF_ERR_CAPACITY, "distance_ratios would pass the 32-bit column index range");
+  return bpf_map3d_set(e, pose_indices.data(), pose_indices.size(), ratios.data(), ratios.size(), min_cells, max_cells,
+                       resolution, max_dist);
+}
+
+int bpf_map3d_get_distances_lut(bpf_engine* e, uint32_t* pose_indices, size_t pose_capacity, size_t* n_pose_indices,
+                                uint8_t* distance_ratios, size_t ratios_capacity, size_t* n_distance_ratios)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_map3d)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 3-D map set");
+  if (n_pose_indices)
+    *n_pose_indices = e->n_pose_indices;
+  if (n_distance_ratios)
+    *n_distance_ratios = e->n_ratios;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (pose_indices)
+  {
+    if (pose_capacity < e->n_pose_indices)
+      return e->fail(BPF_ERR_CAPACITY, "pose_indices output too small");
+    HIPCHK(e, hipMemcpy(pose_indices, e->d_pose_indices.p, e->n_pose_indices * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  if (distance_ratios)
+  {
+    if (ratios_capacity < e->n_ratios)
+      return e->fail(BPF_ERR_CAPACITY, "distance_ratios output too small");
+    HIPCHK(e, hipMemcpy(distance_ratios, e->d_ratios.p, e->n_ratios, hipMemcpyDeviceToHost));
+  }
+  return BPF_OK;
+}
+
+int bpf_cloud_init(bpf_engine* e, int max_beams)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cloud_max_beams = max_beams;
+  if (!e->cloud_configured)
+  {
+    e->cm.off_map_factor = 1.0;  // point_cloud_scanner.cpp:36-38
+    e->cm.tf_quat[3] = 1.0;
+  }
+  return BPF_OK;
+}
+
+int bpf_cloud_set_model(bpf_engine* e, double z_hit, double z_rand, double sigma_hit)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cm.model = BPF_CLOUD_MODEL;
+  e->cloud_z_hit = z_hit;
+  e->cloud_z_rand = z_rand;
+  e->cloud_sigma = sigma_hit;
+  e->cloud_configured = true;
+  return BPF_OK;
+}
+
+int bpf_cloud_set_model_gompertz(bpf_engine* e, double z_hit, double z_rand, double sigma_hit, double gompertz_a,
+                                 double gompertz_b, double gompertz_c, double input_shift, double input_scale,
+                                 double output_shift)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cm.model = BPF_CLOUD_MODEL_GOMPERTZ;
+  e->cm.g = GompertzDev{ gompertz_a, gompertz_b, gompertz_c, input_shift, input_scale, output_shift };
+  e->cloud_z_hit = z_hit;
+  e->cloud_z_rand = z_rand;
+  e->cloud_sigma = sigma_hit;
+  e->cloud_configured = true;
+  return BPF_OK;
+}
+
+int bpf_cloud_set_map_factors(bpf_engine* e, double off_map_factor, double, double)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->cm.off_map_factor = off_map_factor;  // the 3-D recalcWeight only uses this one (:205-229)
+  return BPF_OK;
+}
+
+int bpf_cloud_set_scanner_to_footprint_tf(bpf_engine* e, const double xyz[3], const double quat_xyzw[4])
+{
+  if (!e || !xyz || !quat_xyzw)
+    return BPF_ERR_INVALID_ARGUMENT;
+  std::memcpy(e->cm.tf_xyz, xyz, 3 * sizeof(double));
+  std::memcpy(e->cm.tf_quat, quat_xyzw, 4 * sizeof(double));
+  return BPF_OK;
+}
+
+namespace
+{
+int score_cloud(bpf_engine* e, ParticlesDev p, int n, const float* points_xyz, int n_points)
+{
+  if (!e->have_map3d)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 3-D map set");
+  if (!e->cloud_configured)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "point-cloud model not set");
+  if (!points_xyz || n_points <= 0 || n <= 0)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "empty cloud or sample set");
+  // stage points as float SoA; the table of per-ratio terms follows point_cloud_scanner.cpp:137-159,177-191
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // staging buffers are single-slot
+  HIPCHK(e, e->h_points.reserve((size_t)n_points * 3));
+  HIPCHK(e, e->d_points.reserve((size_t)n_points * 3));
+  for (int q = 0; q < n_points; ++q)
+  {
+    e->h_points.p[q] = points_xyz[3 * q];
+    e->h_points.p[(size_t)n_points + q] = points_xyz[3 * q + 1];
+    e->h_points.p[2 * (size_t)n_points + q] = points_xyz[3 * q + 2];
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_points.p, e->h_points.p, (size_t)n_points * 3 * sizeof(float), hipMemcpyHostToDevice,
+                           e->stream));
+  HIPCHK(e, e->h_cloud_table.reserve(257));
+  HIPCHK(e, e->d_cloud_table.reserve(257));
+  const double denom = 2 * e->cloud_sigma * e->cloud_sigma;
+  const double max_dist = e->map3_max_dist;
+  const double rand_mult = 1.0 / max_dist;  // :140: 1/max_distance, not 1/range_max
+  const double ratio = max_dist / 255;      // max_distance_ratio_, octomap.cpp:58
+  for (int k = 0; k <= 256; ++k)
+  {
+    const double z = (k == 256) ? max_dist : k * ratio;
+    double pz = e->cloud_z_hit * std::exp(-(z * z) / denom);
+    if (e->cm.model == BPF_CLOUD_MODEL)
+    {
+      pz += e->cloud_z_rand * rand_mult;
+      e->h_cloud_table.p[k] = pz * pz * pz;
+    }
+    else
+    {
+      pz += e->cloud_z_rand;
+      e->h_cloud_table.p[k] = pz;
+    }
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_cloud_table.p, e->h_cloud_table.p, 257 * sizeof(double), hipMemcpyHostToDevice,
+                           e->stream));
+  const int n_chunks = blocks_for(n_points, kCloudChunk);
+  HIPCHK(e, e->d_affine.reserve((size_t)n * 12));
+  HIPCHK(e, e->d_cloud_partials.reserve((size_t)n_chunks * n));
+  hipLaunchKernelGGL(k_cloud_affine, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, p, n, e->cm, e->d_affine.p);
+  CloudScoreArgs A{};
+  A.n = n;
+  A.affine = e->d_affine.p;
+  A.points = e->d_points.p;
+  A.n_points = n_points;
+  A.map = e->map3;
+  A.table = e->d_cloud_table.p;
+  A.partials = e->d_cloud_partials.p;
+  A.slabs = std::max(1, std::min(blocks_for(n, 4), std::max(1, (e->n_cu * 6) / n_chunks)));
+  {
+    // exact reciprocal?  1/res must fit 29 bits (so float * rinv is exact) and rinv*res must round to 1
+    const double rinv = e->map3.inv_resolution;
+    uint64_t bits;
+    std::memcpy(&bits, &rinv, 8);
+    const bool exact_rinv = (bits & ((1ull << 24) - 1)) == 0 && std::fabs(std::fma(rinv, e->map3.resolution, -1.0)) < 1.1e-16;
+    ProfScope ps(e, BPF_K_SCORE);
+    if (exact_rinv)
+      hipLaunchKernelGGL(k_cloud_score<true>, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
+    else
+      hipLaunchKernelGGL(k_cloud_score<false>, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
+  }
+  CloudFinishArgs F{};
+  F.p = p;
+  F.n = n;
+  F.partials = e->d_cloud_partials.p;
+  F.n_chunks = n_chunks;
+  F.n_points = n_points;
+  F.map = e->map3;
+  F.model = e->cm;
+  hipLaunchKernelGGL(k_cloud_finish, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, F);
+  HIPCHK(e, hipGetLastError());
+  e->evals_last = (long long)n * n_points;
+  return BPF_OK;
+}
+}  // namespace
+
+double bpf_cloud_apply_model_to_sample_set(bpf_engine* e, double* samples, int sample_count, const float* points_xyz,
+                                           int n_points, int* status)
+{
+  int dummy;
+  if (!status)
+    status = &dummy;
+  *status = BPF_OK;
+  if (!e || !samples)
+  {
+    *status = BPF_ERR_INVALID_ARGUMENT;
+    return 0.0;
+  }
+  if (e->cloud_max_beams < 2)
+    return 0.0;  // point_cloud_scanner.cpp:109-110
+  auto bail = [&](int code) { *status = code; return 0.0; };
+  if (hipSetDevice(e->device) != hipSuccess)
+    return bail(e->fail(BPF_ERR_HIP, "hipSetDevice"));
+  int rc = ensure_scalars(e);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = upload_samples(e, samples, sample_count, e->scratch);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = score_cloud(e, e->scratch.dev(), sample_count, points_xyz, n_points);
+  if (rc != BPF_OK)
+    return bail(rc);
+  rc = sum_into_slot(e, e->scratch.w.p, sample_count, 0, 0, sample_count);
+  if (rc != BPF_OK)
+    return bail(rc);
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(sample_count, 256)), dim3(256), 0, e->stream, e->scratch.dev(),
+                     e->d_aos.p, sample_count);
+  if (hipMemcpyAsync(e->h_aos.p, e->d_aos.p, (size_t)sample_count * sizeof(double4), hipMemcpyDeviceToHost,
+                     e->stream) != hipSuccess ||
+      hipMemcpyAsync(e->h_scalars.p, e->d_scalars.p, sizeof(FilterScalars), hipMemcpyDeviceToHost, e->stream) !=
+          hipSuccess ||
+      hipStreamSynchronize(e->stream) != hipSuccess)
+    return bail(e->fail(BPF_ERR_HIP, "copy back"));
+  for (int i = 0; i < sample_count; ++i)
+    samples[4 * i + 3] = e->h_aos.p[i].w;
+  return e->h_scalars.p->v[0];
+}
+
+int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_points)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_pf)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
+  if (e->cloud_max_beams < 2)
+    return BPF_OK;  // PointCloudScanner::updateSensor returns false (:95-96)
+  HIPCHK(e, hipSetDevice(e->device));
+  SampleSet& s = e->sets[e->cur];
+  const int n = e->sample_count;
+  e->tile_sums_n = -1;
+  int rc = score_cloud(e, s.dev(), n, points_xyz, n_points);
+  if (rc != BPF_OK)
+    return rc;
+  rc = sum_into_slot(e, s.w.p, n, 0, 1, n);
+  if (rc != BPF_OK)
+    return rc;
+  {
+    ProfScope ps(e, BPF_K_NORMALIZE);
+    hipLaunchKernelGGL(k_normalize, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.w.p, n, e->d_scalars.p, 0,
+                       0.0, n);
+  }
+  HIPCHK(e, hipGetLastError());
+  e->last_status = BPF_OK;
+  return BPF_OK;
+}

@@ -1,0 +1,98 @@
+// C-ABI: 2-D map.
+// ---------------------------------------------------------------------- 2-D map
+int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, int size_x, int size_y, float origin_x,
+                  float origin_y, double resolution, double max_dist)
+{
+  if (!e || !cells || size_x <= 0 || size_y <= 0 || !(resolution > 0))
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad map arguments") : BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const size_t ncell = (size_t)size_x * size_y;
+  MapDev& M = e->map;
+  M.size_x = size_x;
+  M.size_y = size_y;
+  M.ltx = (size_x + 2 + 7) / 8 + 1;  // padded cells 0 .. size+1, plus a spare tile column for 8-aligned windows
+  M.lty = (size_y + 2 + 7) / 8;
+  if ((size_t)M.ltx * 16 >= (1u << 24) || (size_t)M.ltx * M.lty * 128 >= (1ull << 32))
+    return e->fail(BPF_ERR_CAPACITY, "map too large for the 32-bit tiled LUT addressing");
+  M.half_x = size_x / 2;
+  M.half_y = size_y / 2;
+  M.origin_x = (double)origin_x;
+  M.origin_y = (double)origin_y;
+  M.resolution = resolution;
+  M.max_dist = max_dist;
+  M.n_levels = 0;
+  e->h_cells8.resize(ncell);
+  for (size_t i = 0; i < ncell; ++i)
+    e->h_cells8[i] = (int8_t)cells[i];
+  // chessboard distance to the nearest blocked cell on the padded grid: two raster sweeps of the
+  // 8-neighbour recurrence D = min(D, neighbour + 1), which is exact for the Chebyshev metric
+  const int pw = size_x + 2, ph = size_y + 2;
+  std::vector<uint16_t> dist((size_t)pw * ph, 0);
+  for (int j = 0; j < size_y; ++j)
+    for (int i = 0; i < size_x; ++i)
+      if (cells[i + (size_t)j * size_x] == -1)
+        dist[(size_t)(j + 1) * pw + (i + 1)] = 0xFFFF;
+  for (int y = 1; y < ph - 1; ++y)
+    for (int x = 1; x < pw - 1; ++x)
+    {
+      uint16_t& d = dist[(size_t)y * pw + x];
+      if (d == 0)
+        continue;
+      const uint16_t* up = &dist[(size_t)(y - 1) * pw + x];
+      uint16_t best = std::min(std::min(up[-1], up[0]), std::min(up[1], (&d)[-1]));
+      best = (uint16_t)std::min<int>(best + 1, 0xFFFF);
+      d = std::min(d, best);
+    }
+  for (int y = ph - 2; y >= 1; --y)
+    for (int x = pw - 2; x >= 1; --x)
+    {
+      uint16_t& d = dist[(size_t)y * pw + x];
+      if (d == 0)
+        continue;
+      const uint16_t* dn = &dist[(size_t)(y + 1) * pw + x];
+      uint16_t best = std::min(std::min(dn[-1], dn[0]), std::min(dn[1], (&d)[1]));
+      best = (uint16_t)std::min<int>(best + 1, 0xFFFF);
+      d = std::min(d, best);
+    }
+  std::vector<uint8_t> cheb((size_t)pw * ph);
+  for (size_t q = 0; q < cheb.size(); ++q)
+    cheb[q] = (uint8_t)std::min<int>(dist[q], 255);
+  HIPCHK(e, e->d_cells8.reserve(ncell));
+  HIPCHK(e, hipMemcpy(e->d_cells8.p, e->h_cells8.data(), ncell, hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_cheb.reserve(cheb.size()));
+  HIPCHK(e, hipMemcpy(e->d_cheb.p, cheb.data(), cheb.size(), hipMemcpyHostToDevice));
+  M.cells8 = e->d_cells8.p;
+  M.cheb = e->d_cheb.p;
+  M.lut_tiles = nullptr;
+  M.levels = nullptr;
+  e->have_map = true;
+  e->have_lut = false;
+  e->map_version++;
+  if (dist_lut)
+    return encode_lut(e, dist_lut);
+  return BPF_OK;
+}
+
+int bpf_map2d_build_distances_lut(bpf_engine* e, double max_dist)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  return build_lut_device(e, max_dist);
+}
+
+int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity)
+{
+  if (!e || !out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_lut)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no distance LUT");
+  const size_t ncell = (size_t)e->map.size_x * e->map.size_y;
+  if (capacity < ncell)
+    return e->fail(BPF_ERR_CAPACITY, "output too small");
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(out, e->d_lut_f32.p, ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return BPF_OK;
+}

@@ -1,0 +1,311 @@
+// Engine state: device / pinned buffers, per-scan staging descriptors, the bpf_engine struct and the
+// HIPCHK error macro.  Part of the one translation unit engine.hip.
+#pragma once
+namespace
+{
+
+constexpr int kRing = 4;            // in-flight scan uploads
+constexpr int kMaxBeams = 4096;     // beams staged in LDS per launch
+constexpr int kTableLdsMax = 2048;  // table entries that still go to LDS
+constexpr int kEventPool = 8192;
+
+// Device / pinned buffers free themselves with the engine (bpf_destroy selects the device first).
+template <typename T>
+struct DevBuf
+{
+  T* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap)
+      return hipSuccess;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t r = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+    if (r == hipSuccess)
+      cap = n;
+    return r;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+template <typename T>
+struct PinnedBuf
+{
+  T* p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { release(); }
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap)
+      return hipSuccess;
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(T), hipHostMallocDefault);
+    if (r == hipSuccess)
+      cap = n;
+    return r;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct SampleSet
+{
+  DevBuf<double> x, y, th, w;
+  ParticlesDev dev() { return ParticlesDev{ x.p, y.p, th.p, w.p }; }
+  hipError_t reserve(size_t n)
+  {
+    hipError_t r;
+    if ((r = x.reserve(n)) != hipSuccess) return r;
+    if ((r = y.reserve(n)) != hipSuccess) return r;
+    if ((r = th.reserve(n)) != hipSuccess) return r;
+    return w.reserve(n);
+  }
+  void release()
+  {
+    x.release(); y.release(); th.release(); w.release();
+  }
+};
+
+struct PlanarModel
+{
+  bool configured = false;
+  int model = BPF_MODEL_LIKELIHOOD_FIELD;
+  int max_beams = 0;
+  double z_hit = 0, z_short = 0, z_max = 0, z_rand = 0, sigma_hit = 0, lambda_short = 0;
+  GompertzDev g{ 0, 0, 0, 0, 0, 0 };
+  int do_beamskip = 0;
+  double beam_skip_distance = 0, beam_skip_threshold = 0, beam_skip_error_threshold = 0;
+  double off_map_factor = 1.0, non_free_factor = 1.0, non_free_radius = 0.0;  // planar_scanner.cpp:42-44
+  double pose[3] = { 0, 0, 0 };
+};
+
+struct ScanSlot
+{
+  PinnedBuf<unsigned char> host;
+  DevBuf<unsigned char> dev;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
+// host-side description of one staged scan (see stage_field_scan)
+struct FieldScan
+{
+  int n_valid = 0;             // beams that pass the range_max / NaN tests
+  int n_staged = 0;            // of those, the ones uploaded (all, or the kept ones of beam skipping)
+  bool copy_pending = false;   // pinned staging not yet copied to the device slot
+  int n_always_off = 0;        // valid beams too long / non-finite to stage: off the map for every pose
+  double off_map_term = 0.0;   // table[K]
+  int n_slots = 0;             // beam_ind range of the prob model
+  std::vector<int> slot_of;    // staged beam -> beam_ind
+  size_t beams_off = 0, table_off = 0, bytes = 0;
+  int table_len = 0;
+};
+
+}  // namespace
+
+struct bpf_engine
+{
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // ---- 2-D map
+  bool have_map = false, have_lut = false;
+  MapDev map{};
+  int map_version = 0;
+  std::vector<int8_t> h_cells8;
+  std::vector<float> h_levels;
+  DevBuf<uint16_t> d_lut_tiles;
+  DevBuf<uint8_t> d_cheb;
+  DevBuf<int8_t> d_cells8;
+  DevBuf<float> d_levels;
+  DevBuf<float> d_lut_f32;
+  DevBuf<int> d_edt_tmp;
+
+  // ---- planar scanner
+  PlanarModel pm;
+  ScanSlot ring[kRing];
+  int ring_next = 0;
+  // host-side caches of scan staging: cos/sin of the bearings (a sensor's bearings are the same
+  // arithmetic sequence scan after scan, node_2d.cpp:559) and the per-level term table (depends
+  // only on the model parameters, range_max and the map)
+  std::vector<double> trig_angles, trig_cos, trig_sin;
+  std::vector<double> term_table;
+  struct TermKey
+  {
+    int model = -1, map_version = -1;
+    double z_hit = 0, z_rand = 0, sigma = 0, range_max = 0;
+    bool operator==(const TermKey& o) const
+    {
+      return model == o.model && map_version == o.map_version && z_hit == o.z_hit && z_rand == o.z_rand &&
+             sigma == o.sigma && range_max == o.range_max;
+    }
+  } term_key;
+  DevBuf<int> d_obs_count;
+  FieldScan skip_fs;          // staging of the counting pass of beam skipping, kept for its second half
+  bool skip_pending = false;
+  // LDS-window scoring path
+  DevBuf<double4> d_prep;
+  DevBuf<double> d_prep_stats, d_chunk_partials;
+  DevBuf<WindowPlan> d_plan;
+  bool window_lds_attr_set = false;
+  bool beam_lds_attr_set = false;
+  bool window_enabled = false;  // measured: no gain on wide clouds; opt-in via BPF_OPT_WINDOW_PATH
+  bool last_used_window_path = false;
+  DevBuf<unsigned long long> d_cells_walked;
+
+  // ---- 3-D map + point-cloud scanner
+  bool have_map3d = false;
+  Map3dDev map3{};
+  double map3_max_dist = 0.0;
+  DevBuf<uint32_t> d_pose_indices;
+  DevBuf<uint8_t> d_ratios;
+  size_t n_pose_indices = 0, n_ratios = 0;
+  bool cloud_configured = false;
+  int cloud_max_beams = 0;
+  double cloud_z_hit = 0, cloud_z_rand = 0, cloud_sigma = 0;
+  CloudModelDev cm{};
+  DevBuf<float> d_affine, d_points;
+  DevBuf<double> d_cloud_partials, d_cloud_table;
+  PinnedBuf<float> h_points;
+  PinnedBuf<double> h_cloud_table;
+
+  // ---- particle filter
+  bool have_pf = false;
+  int min_samples = 0, max_samples = 0;
+  double alpha_slow = 0, alpha_fast = 0, conv_threshold = 0;
+  double pop_err = 0.01, pop_z = 3, dist_threshold = 0.5;  // particle_filter.cpp:58-60
+  int resample_model = BPF_RESAMPLE_MULTINOMIAL;
+  uint64_t rng = 0;  // glibc's unseeded drand48 state
+  LcgJump jump{};
+  SampleSet sets[2];
+  int cur = 0;
+  int sample_count = 0;
+  int leaf_count = 0, bin_count = 0;
+  int converged = 0;
+  float percent_converged = 0;
+  bool converged_pending = false;
+  int conv_n = 0;
+  double w_diff_last = 0;
+  int last_status = BPF_OK;
+  int resample_windows = 0;
+  int window_hint = 4096;
+  long long evals_last = 0;
+  bool cdf_serial = false;
+  bool count_cells = false;
+  KdHistogram hist;
+  SeenKeys seen;
+  DevBuf<double> d_cdf, d_partials, d_targets, d_block_partials, d_tile_sums;
+  int fused_partials = 0;     // > 0: the last scoring launch left that many per-block weight partials
+  int tile_sums_n = -1;       // >= 0: d_tile_sums holds the 2048-tile sums of the current weights for that n
+  DevBuf<FilterScalars> d_scalars;
+  DevBuf<int> d_keys, d_src_index, d_flags;  // d_flags[0] miss, [1] converged count
+  DevBuf<double4> d_aos;
+  PinnedBuf<int> h_keys;
+  PinnedBuf<unsigned> h_done;
+  unsigned done_generation = 0;
+  bool zero_copy_keys = true;
+  PinnedBuf<double> h_targets;
+  hipEvent_t targets_read = nullptr;  // recorded after the sharded systematic window kernel
+  PinnedBuf<int> h_flags;
+  PinnedBuf<FilterScalars> h_scalars;
+  PinnedBuf<double4> h_aos;
+  SampleSet scratch;  // Seam A host-buffer path
+  SampleSet snap;
+  int snap_count = 0, snap_leaf = 0, snap_bins = 0;
+
+  // ---- w_diff > 0: random free-space poses (Node::randomFreeSpacePose) and the draw chain
+  int random_pose_mode = BPF_RANDOM_POSE_NONE;
+  std::vector<float> h_lut_f32;     // the LUT as floats (free-space test: distance > non_free_space_radius)
+  DevBuf<int2> d_free_ij;
+  int n_free = 0;
+  int free_map_version = -1;
+  double free_radius = -1.0;
+  double shard_w_diff = 0.0;        // of the sharded resample in progress (bpf_shard_begin_resample)
+  bool shard_chain = false;         // its draw chain is in d_chain
+  int shard_n_random = 0;           // systematic: random poses at the head of the new set
+  uint64_t shard_rng0 = 0;
+  DevBuf<uint64_t> d_chain_bits;
+  DevBuf<int> d_chain_cnt, d_chain_exit, d_chain_entry, d_chain_base, d_chain;
+  PinnedBuf<int> h_chain_word;
+
+  // ---- KLD stop rule on the device (long draw streams)
+  int kld_device_min = 8192;  // draws left after the first window from which the device tree takes over
+  bool kld_device_used = false;
+  int kld_leaf = 0, kld_bins = 0;
+  DevBuf<unsigned long long> d_kld_hkey;
+  DevBuf<int> d_kld_htmin, d_kld_slot, d_kld_cur, d_kld_first, d_kld_child, d_kld_flags, d_kld_limit;
+  DevBuf<int2> d_kld_delta, d_kld_tiles, d_kld_counts;
+  PinnedBuf<int> h_kld;
+  std::vector<int> kld_limit_host;
+  double kld_limit_key[4] = { -1, -1, -1, -1 };  // pop_err, pop_z, min_samples, max_samples of the cached table
+
+  // ---- motion model
+  int odom_model = BPF_ODOM_MODEL_DIFF;
+  double odom_alpha[5] = { 0, 0, 0, 0, 0 };
+  bool odom_configured = false;
+  DevBuf<int> d_motion_counts;
+  DevBuf<long long> d_motion_offsets, d_motion_result;
+  DevBuf<double> d_gauss, d_init_rot;
+  PinnedBuf<long long> h_motion_result;
+
+  // ---- cluster statistics (host, lazy)
+  std::vector<bpf_cluster> clusters;
+  double set_mean[3] = { 0, 0, 0 }, set_cov[5] = { 0, 0, 0, 0, 0 };
+  long long stats_epoch = -1;   // value of set_epoch the statistics were computed for
+  long long set_epoch = 0;      // bumped whenever the current set's poses / weights change
+  bool hist_matches_set = false;
+
+  // ---- profiling
+  bool profiling = false;
+  bool profile_all = false;
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  std::vector<int> ev_class;
+  size_t ev_used = 0;
+  bpf_profile prof{};
+
+  int fail(int code, const std::string& msg)
+  {
+    last_error = msg;
+    last_status = code;
+    return code;
+  }
+  int fail_hip(hipError_t r, const char* what)
+  {
+    return fail(BPF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(r));
+  }
+};
+
+#define HIPCHK(e, call)                          \
+  do                                             \
+  {                                              \
+    hipError_t _r = (call);                      \
+    if (_r != hipSuccess)                        \
+      return (e)->fail_hip(_r, #call);           \
+  } while (0)

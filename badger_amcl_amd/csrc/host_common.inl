@@ -1,0 +1,145 @@
+// Host helpers shared by every part of the engine: profiling scopes, drand48 jump tables, LUT encoding.
+// ------------------------------------------------------------------ profiling helpers
+struct ProfScope
+{
+  bpf_engine* e;
+  int idx = -1;
+  ProfScope(bpf_engine* eng, int klass) : e(eng)
+  {
+    if (!e->profiling || e->ev_used >= e->ev_start.size() ||
+        (klass != BPF_K_SCORE && klass != BPF_K_SCORE_WINDOW && !e->profile_all))
+      return;
+    idx = (int)e->ev_used++;
+    e->ev_class[idx] = klass;
+    (void)hipEventRecord(e->ev_start[idx], e->stream);
+  }
+  ~ProfScope()
+  {
+    if (idx >= 0)
+      (void)hipEventRecord(e->ev_stop[idx], e->stream);
+  }
+};
+
+void lcg_tables(LcgJump& J)
+{
+  const uint64_t mask = (1ull << 48) - 1;
+  uint64_t a = 0x5DEECE66Dull, c = 0xBull;
+  for (int j = 0; j < 48; ++j)
+  {
+    J.A[j] = a;
+    J.C[j] = c;
+    c = (c * a + c) & mask;  // apply the step twice: x -> a*(a*x + c) + c
+    a = (a * a) & mask;
+  }
+}
+
+uint64_t lcg_skip_host(uint64_t x0, uint64_t n, const LcgJump& J)
+{
+  const uint64_t mask = (1ull << 48) - 1;
+  uint64_t a = 1, c = 0;
+  for (int j = 0; n != 0 && j < 48; ++j, n >>= 1)
+    if (n & 1)
+    {
+      a = (a * J.A[j]) & mask;
+      c = (c * J.A[j] + J.C[j]) & mask;
+    }
+  return (a * x0 + c) & mask;
+}
+
+int blocks_for(int n, int per_block)
+{
+  return (n + per_block - 1) / per_block;
+}
+
+// ------------------------------------------------------------------ map encoding
+int encode_lut(bpf_engine* e, const float* lut)
+{
+  const int sx = e->map.size_x, sy = e->map.size_y;
+  const size_t ncell = (size_t)sx * sy;
+  std::unordered_map<uint32_t, int> seen;
+  seen.reserve(4096);
+  std::vector<float> levels;
+  uint32_t last_bits = 0;
+  bool have_last = false;
+  for (size_t i = 0; i < ncell; ++i)
+  {
+    uint32_t bits;
+    std::memcpy(&bits, &lut[i], 4);
+    if (have_last && bits == last_bits)
+      continue;
+    last_bits = bits;
+    have_last = true;
+    if (seen.emplace(bits, 0).second)
+    {
+      levels.push_back(lut[i]);
+      if (levels.size() > 8190)
+        return e->fail(BPF_ERR_LUT_LEVELS, "distance LUT holds more than 8190 distinct values");
+    }
+  }
+  std::sort(levels.begin(), levels.end());
+  for (size_t k = 0; k < levels.size(); ++k)
+  {
+    uint32_t bits;
+    std::memcpy(&bits, &levels[k], 4);
+    seen[bits] = (int)k;
+  }
+  // padded image: a border cell all round, everything outside the map holds the off-map level K;
+  // entries are level*8 (byte offset of the level's term in the per-scan table)
+  const int tx = e->map.ltx, ty = e->map.lty;
+  const uint16_t off_map_level = (uint16_t)(levels.size() * 8);
+  std::vector<uint16_t> tiles((size_t)tx * ty * 64, off_map_level);
+  for (int j = 0; j < sy; ++j)
+  {
+    uint32_t prev_bits = 0;
+    int prev_idx = -1;
+    for (int i = 0; i < sx; ++i)
+    {
+      uint32_t bits;
+      std::memcpy(&bits, &lut[i + (size_t)j * sx], 4);
+      if (prev_idx < 0 || bits != prev_bits)
+      {
+        prev_idx = seen[bits];
+        prev_bits = bits;
+      }
+      const int u = i + 1, v = j + 1;
+      tiles[((size_t)(v >> 3) * tx + (u >> 3)) * 64 + ((u & 7) << 3) + (v & 7)] = (uint16_t)(prev_idx * 8);
+    }
+  }
+  HIPCHK(e, e->d_lut_tiles.reserve(tiles.size()));
+  HIPCHK(e, hipMemcpy(e->d_lut_tiles.p, tiles.data(), tiles.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_levels.reserve(levels.size() + 1));
+  HIPCHK(e, hipMemcpy(e->d_levels.p, levels.data(), levels.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_lut_f32.reserve(ncell));
+  HIPCHK(e, hipMemcpy(e->d_lut_f32.p, lut, ncell * sizeof(float), hipMemcpyHostToDevice));
+  e->h_levels = levels;
+  e->h_lut_f32.assign(lut, lut + ncell);
+  e->map.lut_tiles = e->d_lut_tiles.p;
+  e->map.levels = e->d_levels.p;
+  e->map.n_levels = (int)levels.size();
+  e->have_lut = true;
+  e->map_version++;
+  return BPF_OK;
+}
+
+int build_lut_device(bpf_engine* e, double max_dist)
+{
+  if (!e->have_map)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
+  if (max_dist == 0.0)
+    return BPF_OK;  // occupancy_map.cpp:141-145: leaves the LUT untouched
+  const int sx = e->map.size_x, sy = e->map.size_y;
+  const size_t ncell = (size_t)sx * sy;
+  const int radius = (int)std::floor(max_dist / e->map.resolution);
+  HIPCHK(e, e->d_edt_tmp.reserve(ncell));
+  HIPCHK(e, e->d_lut_f32.reserve(ncell));
+  dim3 grid(blocks_for(sx, 256), sy), block(256);
+  hipLaunchKernelGGL(k_edt_rows, grid, block, 0, e->stream, e->d_cells8.p, sx, sy, radius, e->d_edt_tmp.p);
+  hipLaunchKernelGGL(k_edt_cols, grid, block, 0, e->stream, e->d_edt_tmp.p, sx, sy, radius, e->map.resolution,
+                     max_dist, e->d_lut_f32.p);
+  HIPCHK(e, hipGetLastError());
+  std::vector<float> lut(ncell);
+  HIPCHK(e, hipMemcpyAsync(lut.data(), e->d_lut_f32.p, ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->map.max_dist = max_dist;
+  return encode_lut(e, lut.data());
+}

@@ -1,0 +1,553 @@
+// Host half of normalisation and resampling: CDF, updateConverged, free-space list and draw chain (recovery),
+// KLD stop rule (device tree and ordered host replay), multinomial and systematic resamplers.
+int fetch_scalars(bpf_engine* e)
+{
+  HIPCHK(e, hipMemcpyAsync(e->h_scalars.p, e->d_scalars.p, sizeof(FilterScalars), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->h_flags.p, e->d_flags.p, 8 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (e->converged_pending)
+  {
+    // particle_filter.cpp:206-219, float arithmetic for the percentage
+    const double pct = (float)e->h_flags.p[1] / (float)e->conv_n * 100;
+    e->percent_converged = (float)pct;
+    e->converged = pct >= e->conv_threshold;
+    e->converged_pending = false;
+  }
+  return BPF_OK;
+}
+
+int build_cdf(bpf_engine* e, const double* w, int n)
+{
+  HIPCHK(e, e->d_cdf.reserve((size_t)n + 1));
+  ProfScope ps(e, BPF_K_CDF);
+  if (e->cdf_serial)
+  {
+    hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, e->stream, w, n, e->d_cdf.p);
+    HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
+  }
+  else
+  {
+    const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+    double* tiles;
+    if (e->tile_sums_n == n && w == e->sets[e->cur].w.p)
+    {
+      tiles = e->d_tile_sums.p;  // left behind by k_normalize_fused; consumed (scanned in place) here
+      e->tile_sums_n = -1;
+    }
+    else
+    {
+      HIPCHK(e, e->d_partials.reserve((size_t)nb));
+      tiles = e->d_partials.p;
+      hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles);
+    }
+    if (nb <= 256)
+    {
+      // few tiles: every block of the final pass forms its own offset (one launch less)
+      hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 0, e->d_cdf.p,
+                         e->d_flags.p);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, tiles, nb, e->d_flags.p);
+      hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 1, e->d_cdf.p,
+                         nullptr);
+    }
+  }
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+// updateConverged (particle_filter.cpp:170-220) on the current set, result fetched lazily
+int launch_converged(bpf_engine* e)
+{
+  SampleSet& s = e->sets[e->cur];
+  const int n = e->sample_count;
+  int rcode = sum_into_slot(e, s.x.p, n, 3, 0, n);
+  if (rcode != BPF_OK)
+    return rcode;
+  rcode = sum_into_slot(e, s.y.p, n, 4, 0, n);
+  if (rcode != BPF_OK)
+    return rcode;
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p + 1, 0, sizeof(int), e->stream));
+  const int grid = std::max(1, std::min(blocks_for(n, 256), 1024));
+  hipLaunchKernelGGL(k_count_converged, dim3(grid), dim3(256), 0, e->stream, s.x.p, s.y.p, n, e->d_scalars.p,
+                     e->dist_threshold, e->d_flags.p + 1);
+  HIPCHK(e, hipGetLastError());
+  e->converged_pending = true;
+  e->conv_n = n;
+  return BPF_OK;
+}
+
+// Node2D::updateFreeSpaceIndices (node_2d.cpp:317-337) for the current map and non_free_space_radius, cached
+int ensure_free_space(bpf_engine* e, FreeSpaceDev* out)
+{
+  if (e->random_pose_mode != BPF_RANDOM_POSE_FREE_SPACE_2D)
+    return e->fail(BPF_ERR_UNSUPPORTED,
+                   "w_diff > 0: random pose injection needs a pose generator (bpf_pf_set_random_pose_generator); "
+                   "the node's random_pose_fn_ callback (particle_filter.cpp:385-388) cannot be called from here");
+  if (!e->have_map || !e->have_lut)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "random free-space poses need the 2-D map and its distance LUT");
+  const double radius = e->pm.non_free_radius;
+  if (e->free_map_version != e->map_version || e->free_radius != radius)
+  {
+    const int sx = e->map.size_x, sy = e->map.size_y;
+    std::vector<int2> ij;
+    ij.reserve((size_t)sx * sy / 2);
+    for (int i = 0; i < sx; ++i)
+      for (int j = 0; j < sy; ++j)
+      {
+        const size_t idx = i + (size_t)j * sx;
+        if (e->h_cells8[idx] == -1 && (double)e->h_lut_f32[idx] > radius)
+          ij.push_back(make_int2(i, j));
+      }
+    e->n_free = (int)ij.size();
+    HIPCHK(e, e->d_free_ij.reserve(std::max<size_t>(ij.size(), 1)));
+    if (!ij.empty())
+      HIPCHK(e, hipMemcpy(e->d_free_ij.p, ij.data(), ij.size() * sizeof(int2), hipMemcpyHostToDevice));
+    e->free_map_version = e->map_version;
+    e->free_radius = radius;
+  }
+  if (e->n_free <= 0)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "the map has no free cell to draw random poses from");
+  out->ij = e->d_free_ij.p;
+  out->n = e->n_free;
+  out->size_x = e->map.size_x;
+  out->size_y = e->map.size_y;
+  out->origin_x = e->map.origin_x;
+  out->origin_y = e->map.origin_y;
+  out->resolution = e->map.resolution;
+  return BPF_OK;
+}
+
+// Where every candidate draw 0 .. max_draws finds its stream elements when w_diff > 0 (kernels_recovery.hpp)
+int build_draw_chain(bpf_engine* e, double w_diff, int max_draws)
+{
+  const long long positions = 3ll * ((long long)max_draws + 1) + 3;
+  if (positions >= 0x7fffffffll)
+    return e->fail(BPF_ERR_CAPACITY, "draw chain would pass 31-bit stream positions");
+  const int n_seg = (int)((positions + kChainSeg - 1) / kChainSeg);
+  HIPCHK(e, e->d_chain_bits.reserve((size_t)2 * n_seg));
+  HIPCHK(e, e->d_chain_cnt.reserve((size_t)3 * n_seg));
+  HIPCHK(e, e->d_chain_exit.reserve((size_t)3 * n_seg));
+  HIPCHK(e, e->d_chain_entry.reserve((size_t)n_seg));
+  HIPCHK(e, e->d_chain_base.reserve((size_t)n_seg));
+  HIPCHK(e, e->d_chain.reserve((size_t)max_draws + 1));
+  ChainArgs C{};
+  C.rng_state = e->rng;
+  C.w_diff = w_diff;
+  C.n_seg = n_seg;
+  C.max_draws = max_draws;
+  C.seg_bits = e->d_chain_bits.p;
+  C.seg_cnt = e->d_chain_cnt.p;
+  C.seg_exit = e->d_chain_exit.p;
+  C.seg_entry = e->d_chain_entry.p;
+  C.seg_base = e->d_chain_base.p;
+  C.chain = e->d_chain.p;
+  C.jump = e->jump;
+  ProfScope ps(e, BPF_K_DRAW);
+  hipLaunchKernelGGL(k_chain_segments, dim3(blocks_for(n_seg, 256)), dim3(256), 0, e->stream, C);
+  hipLaunchKernelGGL(k_chain_scan, dim3(1), dim3(1024), 0, e->stream, C);
+  hipLaunchKernelGGL(k_chain_emit, dim3(blocks_for(n_seg, 256)), dim3(256), 0, e->stream, C);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+// The KLD stop rule for the whole candidate stream [0, maxs) on the device (kernels_kld.hpp), keys in
+// e->d_keys (AoS): grows the histogram tree level by level and scans the leaf count.
+// Returns BPF_OK with *stop_out = stop count (or -1: no stop), *leaf_out / *bins_out at the final count;
+// *handled = false when a key does not fit the 64-bit packing or the tree is deeper than the level budget
+// (the caller then replays on the host as before).
+int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out,
+                       bool whole_stream = false)
+{
+  *handled = false;
+  const int n = maxs;
+  if (n >= (1 << 30))
+    return BPF_OK;  // element indices 2v + side are folded as 32-bit tags
+  // resampleLimit per leaf count, cached per parameter set (host libm, as the reference evaluates it)
+  if (e->kld_limit_key[0] != e->pop_err || e->kld_limit_key[1] != e->pop_z || e->kld_limit_key[2] != e->min_samples ||
+      e->kld_limit_key[3] != e->max_samples || (int)e->kld_limit_host.size() < n + 1)
+  {
+    e->kld_limit_host.resize((size_t)n + 1);
+    for (int k = 0; k <= n; ++k)
+      e->kld_limit_host[k] = resample_limit(k, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+    HIPCHK(e, e->d_kld_limit.reserve((size_t)n + 1));
+    HIPCHK(e, hipMemcpyAsync(e->d_kld_limit.p, e->kld_limit_host.data(), ((size_t)n + 1) * sizeof(int),
+                             hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->kld_limit_key[0] = e->pop_err;
+    e->kld_limit_key[1] = e->pop_z;
+    e->kld_limit_key[2] = e->min_samples;
+    e->kld_limit_key[3] = e->max_samples;
+  }
+  unsigned table = 1024;
+  while (table < 2u * (unsigned)n)
+    table <<= 1;
+  constexpr int kMaxLevels = 256;
+  const int tiles = blocks_for(n, kKldTile);
+  HIPCHK(e, e->d_kld_hkey.reserve(table));
+  HIPCHK(e, e->d_kld_htmin.reserve(table));
+  HIPCHK(e, e->d_kld_slot.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_cur.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_first.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_child.reserve((size_t)2 * n));
+  HIPCHK(e, e->d_kld_delta.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_counts.reserve((size_t)n));
+  HIPCHK(e, e->d_kld_tiles.reserve((size_t)tiles));
+  HIPCHK(e, e->d_kld_flags.reserve(4 + kMaxLevels));
+  HIPCHK(e, e->h_kld.reserve(4 + kMaxLevels));
+  ProfScope ps(e, BPF_K_DRAW);
+  HIPCHK(e, hipMemsetAsync(e->d_kld_hkey.p, 0xFF, (size_t)table * sizeof(unsigned long long), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_htmin.p, 0x7F, (size_t)table * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_first.p, 0x7F, (size_t)n * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_child.p, 0x7F, (size_t)2 * n * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_flags.p, 0, (4 + kMaxLevels) * sizeof(int), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_kld_flags.p + 2, 0x7F, sizeof(int), e->stream));
+  KldArgs K{};
+  K.keys = e->d_keys.p;
+  K.n = n;
+  K.h_key = e->d_kld_hkey.p;
+  K.h_tmin = e->d_kld_htmin.p;
+  K.h_mask = table - 1;
+  K.slot = e->d_kld_slot.p;
+  K.cur = e->d_kld_cur.p;
+  K.first = e->d_kld_first.p;
+  K.child = e->d_kld_child.p;
+  K.delta = e->d_kld_delta.p;
+  K.flags = e->d_kld_flags.p;
+  K.limit = e->d_kld_limit.p;
+  const dim3 grid(blocks_for(n, 256)), block(256);
+  hipLaunchKernelGGL(k_kld_hash, grid, block, 0, e->stream, K);
+  hipLaunchKernelGGL(k_kld_init, grid, block, 0, e->stream, K);
+  hipLaunchKernelGGL(k_kld_root_first, dim3(1), dim3(1024), 0, e->stream, K);
+  int level = 0;
+  bool done = false;
+  while (!done && level < kMaxLevels)
+  {
+    const int batch = (level == 0) ? 32 : 16;
+    for (int q = 0; q < batch && level < kMaxLevels; ++q, ++level)
+    {
+      hipLaunchKernelGGL(k_kld_children, dim3(blocks_for(n, kKldBlock)), dim3(kKldBlock), 0, e->stream, K);
+      hipLaunchKernelGGL(k_kld_descend, dim3(blocks_for(n, kKldBlock)), dim3(kKldBlock), 0, e->stream, K,
+                         e->d_kld_flags.p + 4 + level);
+    }
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(e->h_kld.p, e->d_kld_flags.p, (4 + kMaxLevels) * sizeof(int), hipMemcpyDeviceToHost,
+                             e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->h_kld.p[0] != 0)
+      return BPF_OK;  // a key outside the packing range: not handled
+    done = e->h_kld.p[4 + level - 1] == 0;
+  }
+  if (getenv("BPF_DEBUG"))
+    fprintf(stderr, "[kld device] n %d levels %d done %d\n", n, level, (int)done);
+  if (!done)
+    return BPF_OK;  // deeper than the level budget: not handled
+  hipLaunchKernelGGL(k_kld_scan_tiles, dim3(tiles), dim3(256), 0, e->stream, (const int2*)e->d_kld_delta.p, n,
+                     e->d_kld_tiles.p);
+  hipLaunchKernelGGL(k_kld_scan_offsets, dim3(1), dim3(1024), 0, e->stream, e->d_kld_tiles.p, tiles);
+  hipLaunchKernelGGL(k_kld_scan_final, dim3(tiles), dim3(256), 0, e->stream, K, (const int2*)e->d_kld_tiles.p,
+                     e->d_kld_counts.p);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(e->h_kld.p, e->d_kld_flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const int stop = whole_stream ? -1 : e->h_kld.p[2];  // whole_stream: the tree of all n keys, no stop rule
+  const int M = (stop >= 1 && stop <= n) ? stop : n;
+  int2 c;
+  HIPCHK(e, hipMemcpyAsync(&c, e->d_kld_counts.p + (M - 1), sizeof(int2), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  *stop_out = (stop >= 1 && stop <= n) ? stop : -1;
+  *leaf_out = c.x;
+  *bins_out = c.y;
+  *handled = true;
+  return BPF_OK;
+}
+
+// the whole candidate stream [0, maxs) again with the keys on the device only, then the tree
+int kld_on_device(bpf_engine* e, DrawArgs A, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out)
+{
+  A.m0 = 0;
+  A.m1 = maxs;
+  A.host_keys = nullptr;
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(maxs, 256)), dim3(256), 0, e->stream, A);
+  }
+  return kld_tree_on_device(e, maxs, handled, stop_out, leaf_out, bins_out);
+}
+
+// Spin on the generation word a kernel publishes in pinned host memory (kernels of ~10 us); false if it
+// takes implausibly long, and the caller falls back to a copy + stream synchronisation.
+bool wait_generation(bpf_engine* e, unsigned generation)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins)
+  {
+    if (__atomic_load_n(e->h_done.p, __ATOMIC_ACQUIRE) == generation)
+      return true;
+    if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+      return false;
+    __builtin_ia32_pause();
+  }
+}
+
+int resample_multinomial(bpf_engine* e, double w_diff)
+{
+  SampleSet& a = e->sets[e->cur];
+  SampleSet& b = e->sets[e->cur ^ 1];
+  const int n = e->sample_count;
+  const int maxs = e->max_samples;
+  FreeSpaceDev free_space{};
+  const int* chain = nullptr;
+  if (w_diff > 0.0)
+  {
+    // :383-388: every draw first tests a uniform against w_diff; where each draw finds its stream elements is
+    // resolved up front for all candidate draws
+    int rcf = ensure_free_space(e, &free_space);
+    if (rcf != BPF_OK)
+      return rcf;
+    rcf = build_draw_chain(e, w_diff, maxs);
+    if (rcf != BPF_OK)
+      return rcf;
+    chain = e->d_chain.p;
+  }
+  HIPCHK(e, e->d_keys.reserve((size_t)maxs * 3));
+  HIPCHK(e, e->d_src_index.reserve((size_t)maxs));
+  HIPCHK(e, e->h_keys.reserve((size_t)maxs * 3));
+  e->hist.clear();
+  e->seen.reset((size_t)std::min(maxs, 1 << 20));
+  int m0 = 0, stop = -1;
+  int window = std::max(1024, std::min(e->window_hint, maxs));
+  e->resample_windows = 0;
+  int cached_leaf = -1, cached_limit = 0;
+  e->kld_device_used = false;
+  bool device_declined = false;
+  // keep the host's first window short when the device tree can take over after it
+  if (window > 4096 && maxs - 4096 >= e->kld_device_min)
+    window = 4096;
+  while (m0 < maxs && stop < 0)
+  {
+    const int m1 = std::min(maxs, m0 + window);
+    DrawArgs A{};
+    A.src = a.dev();
+    A.n_src = n;
+    A.cdf = e->d_cdf.p;
+    A.dst = b.dev();
+    A.m0 = m0;
+    A.m1 = m1;
+    A.rng_state = e->rng;
+    A.jump = e->jump;
+    A.keys = e->d_keys.p;
+    A.src_index = e->d_src_index.p;
+    A.miss_flag = e->d_flags.p;
+    A.sharded = 0;
+    A.chain = chain;
+    A.free_space = free_space;
+    // long stream ahead: either the first window found no stop, or the previous cycle ran to the end
+    const bool long_stream = (m0 > 0 || e->window_hint >= maxs) && maxs - m0 >= e->kld_device_min;
+    if (long_stream && !device_declined)
+    {
+      // no stop inside the first window and a long stream ahead (a spread cloud): the ordered replay moves
+      // to the device for the whole stream
+      bool handled = false;
+      int dstop = -1, dleaf = 0, dbins = 0;
+      int rc = kld_on_device(e, A, maxs, &handled, &dstop, &dleaf, &dbins);
+      if (rc != BPF_OK)
+        return rc;
+      if (handled)
+      {
+        e->resample_windows++;
+        stop = dstop;
+        e->kld_device_used = true;
+        e->kld_leaf = dleaf;
+        e->kld_bins = dbins;
+        break;
+      }
+      device_declined = true;  // key range or depth outside what the device tree takes: host replay as before
+    }
+    const int wn = m1 - m0;
+    // Keys go straight into pinned host memory and the last block publishes a generation number
+    // there: the host polls that word instead of paying for a copy plus a stream synchronisation.
+    const bool zero_copy = e->zero_copy_keys && wn <= (1 << 20);
+    if (zero_copy)
+    {
+      A.host_keys = e->h_keys.p;
+      A.host_stride = wn;
+      A.done_counter = reinterpret_cast<unsigned*>(e->d_flags.p + 4);
+      A.host_done = reinterpret_cast<volatile unsigned*>(e->h_done.p);
+      A.generation = ++e->done_generation;
+    }
+    {
+      ProfScope ps(e, BPF_K_DRAW);
+      hipLaunchKernelGGL(k_draw_select, dim3(blocks_for(wn, 256)), dim3(256), 0, e->stream, A);
+    }
+    HIPCHK(e, hipGetLastError());
+    const bool have_keys = zero_copy && wait_generation(e, A.generation);
+    int k_stride = wn;
+    if (!have_keys)
+    {
+      HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)wn * 3 * sizeof(int), hipMemcpyDeviceToHost,
+                               e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      k_stride = 0;  // AoS triples from the device buffer
+    }
+    e->resample_windows++;
+    const int* keys = e->h_keys.p;
+    for (int m = m0; m < m1; ++m)
+    {
+      const int o = m - m0;
+      const int k[3] = { k_stride ? keys[o] : keys[3 * o], k_stride ? keys[k_stride + o] : keys[3 * o + 1],
+                         k_stride ? keys[2 * k_stride + o] : keys[3 * o + 2] };
+      if (e->seen.first_time(k[0], k[1], k[2]))
+      {
+        e->hist.insert(k[0], k[1], k[2]);
+        const int lc = e->hist.leaf_count();
+        if (lc != cached_leaf)
+        {
+          cached_leaf = lc;
+          cached_limit = resample_limit(lc, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+        }
+      }
+      if (m + 1 > cached_limit)  // particle_filter.cpp:416
+      {
+        stop = m + 1;
+        break;
+      }
+    }
+    m0 = m1;
+    window *= 4;
+  }
+  const int M = (stop > 0) ? stop : maxs;
+  // the window that found the stop also inserted nothing past it: hist is exactly set b's tree
+  if (chain != nullptr)
+  {
+    // the stream was consumed up to the element before draw M's test
+    HIPCHK(e, e->h_chain_word.reserve(1));
+    HIPCHK(e, hipMemcpyAsync(e->h_chain_word.p, chain + M, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const unsigned next_test = (unsigned)e->h_chain_word.p[0] & 0x7fffffffu;
+    e->rng = lcg_skip_host(e->rng, (uint64_t)next_test - 1ull, e->jump);
+  }
+  else
+    e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)M, e->jump);
+  e->window_hint = std::max(1024, ((M + M / 4) + 1023) / 1024 * 1024);
+  e->sample_count = M;
+  return BPF_OK;
+}
+
+int resample_systematic(bpf_engine* e, double w_diff)
+{
+  SampleSet& a = e->sets[e->cur];
+  SampleSet& b = e->sets[e->cur ^ 1];
+  const int n = e->sample_count;
+  int count = resample_limit(e->leaf_count, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
+  FreeSpaceDev free_space{};
+  int num_random = 0;
+  if (w_diff > 0.0)
+  {
+    // particle_filter.cpp:295-306: room for random poses on top of the systematic ones
+    count *= (1.0 + w_diff);
+    if (count > e->max_samples)
+      count = e->max_samples;
+    num_random = (int)(w_diff * count);
+    if (num_random > 0)
+    {
+      int rcf = ensure_free_space(e, &free_space);
+      if (rcf != BPF_OK)
+        return rcf;
+    }
+  }
+  const int num_systematic = count - num_random;
+  const uint64_t rng_before = e->rng;
+  e->rng = lcg_skip_host(e->rng, 1, e->jump);
+  const double start = std::ldexp((double)e->rng, -48);
+  const double delta = 1.0 / num_systematic;
+  HIPCHK(e, e->d_keys.reserve((size_t)e->max_samples * 3));
+  HIPCHK(e, e->d_src_index.reserve((size_t)e->max_samples));
+  HIPCHK(e, e->h_keys.reserve((size_t)e->max_samples * 3));
+  SystematicArgs A{};
+  A.src = a.dev();
+  A.n_src = n;
+  A.cdf = e->d_cdf.p;
+  A.dst = b.dev();
+  A.count = count;
+  A.n_random = num_random;
+  A.rng_state = rng_before;
+  A.jump = e->jump;
+  A.free_space = free_space;
+  A.keys = e->d_keys.p;
+  A.src_index = e->d_src_index.p;
+  A.miss_flag = e->d_flags.p;
+  // The targets are a serial floating-point chain (particle_filter.cpp:337-341): target += delta, and
+  // target -= 1 once it passes 1.  A CPU core runs that dependency chain several times faster than a
+  // GPU lane, with the same IEEE arithmetic, so the host forms the targets and uploads them.
+  HIPCHK(e, e->h_targets.reserve((size_t)e->max_samples));
+  {
+    double t = start;
+    double* out = e->h_targets.p;
+    for (int i = 0; i < num_systematic; ++i)
+    {
+      out[i] = t;
+      t += delta;
+      if (t > 1.0)
+        t -= 1.0;
+    }
+  }
+  // the kernel reads the targets straight from the pinned buffer (28 KB for 3.5 k samples) and, like the
+  // multinomial draw kernel, leaves the keys in pinned memory behind a generation word
+  A.targets = e->h_targets.p;
+  const bool zero_copy = e->zero_copy_keys && count <= (1 << 20);
+  if (zero_copy)
+  {
+    A.host_keys = e->h_keys.p;
+    A.host_stride = count;
+    A.done_counter = reinterpret_cast<unsigned*>(e->d_flags.p + 4);
+    A.host_done = reinterpret_cast<volatile unsigned*>(e->h_done.p);
+    A.generation = ++e->done_generation;
+  }
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_systematic_select, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream, A);
+  }
+  HIPCHK(e, hipGetLastError());
+  int k_stride = count;
+  if (!(zero_copy && wait_generation(e, A.generation)))
+  {
+    if (zero_copy)  // the kernel wrote the host rows; wait for it the slow way
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+    else
+    {
+      HIPCHK(e, hipMemcpyAsync(e->h_keys.p, e->d_keys.p, (size_t)count * 3 * sizeof(int), hipMemcpyDeviceToHost,
+                               e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      k_stride = 0;
+    }
+  }
+  e->hist.clear();
+  e->seen.reset((size_t)std::min(count, 1 << 20));
+  const int* keys = e->h_keys.p;
+  for (int m = 0; m < count; ++m)
+  {
+    const int k0 = k_stride ? keys[m] : keys[3 * m], k1 = k_stride ? keys[k_stride + m] : keys[3 * m + 1],
+              k2 = k_stride ? keys[2 * k_stride + m] : keys[3 * m + 2];
+    if (e->seen.first_time(k0, k1, k2))
+      e->hist.insert(k0, k1, k2);
+  }
+  // :316-324: the random poses took two uniforms each, right after the systematic start
+  e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)num_random, e->jump);
+  e->resample_windows = 1;
+  e->sample_count = count;
+  return BPF_OK;
+}
+
+int upload_samples(bpf_engine* e, const double* aos, int n, SampleSet& dst)
+{
+  HIPCHK(e, e->h_aos.reserve((size_t)n));
+  HIPCHK(e, e->d_aos.reserve((size_t)n));
+  HIPCHK(e, dst.reserve((size_t)n));
+  std::memcpy(e->h_aos.p, aos, (size_t)n * sizeof(double4));
+  HIPCHK(e, hipMemcpyAsync(e->d_aos.p, e->h_aos.p, (size_t)n * sizeof(double4), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->d_aos.p, dst.dev(), n);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}

@@ -1,0 +1,523 @@
+// Host half of the planar scoring path: scan staging ring, beam / term tables, kernel launches, beam skipping.
+// ------------------------------------------------------------------ scan staging
+int acquire_slot(bpf_engine* e, size_t bytes, ScanSlot** out)
+{
+  ScanSlot& s = e->ring[e->ring_next];
+  e->ring_next = (e->ring_next + 1) % kRing;
+  if (s.pending)
+  {
+    HIPCHK(e, hipEventSynchronize(s.done));
+    s.pending = false;
+  }
+  if (!s.done)
+    HIPCHK(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  HIPCHK(e, s.host.reserve((bytes + 31) & ~(size_t)15));  // whole 16-byte words are copied
+  HIPCHK(e, s.dev.reserve((bytes + 31) & ~(size_t)15));
+  *out = &s;
+  return BPF_OK;
+}
+
+int release_slot(bpf_engine* e, ScanSlot* s)
+{
+  HIPCHK(e, hipEventRecord(s->done, e->stream));
+  s->pending = true;
+  return BPF_OK;
+}
+
+// Host half of calcLikelihoodFieldModel{,Prob,Gompertz}: beam decimation and validity
+// (planar_scanner.cpp:265-282, :339-343,410-425, :578-597) and the per-level term table.
+int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, int rc, double range_max,
+                     ScanSlot** slot_out, FieldScan* fs, const std::vector<uint8_t>* keep_slot = nullptr)
+{
+  const PlanarModel& pm = e->pm;
+  int step;
+  if (pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB)
+    step = (int)std::ceil(rc / (double)pm.max_beams);
+  else
+    step = (rc - 1) / (pm.max_beams - 1);
+  if (step < 1)
+    step = 1;
+  const int K = e->map.n_levels;
+  fs->table_len = K + 1;
+  if ((int)e->trig_angles.size() != rc || std::memcmp(e->trig_angles.data(), angles, (size_t)rc * sizeof(double)) != 0)
+  {
+    e->trig_angles.assign(angles, angles + rc);
+    e->trig_cos.resize(rc);
+    e->trig_sin.resize(rc);
+    for (int i = 0; i < rc; ++i)
+    {
+      e->trig_cos[i] = std::cos(angles[i]);
+      e->trig_sin[i] = std::sin(angles[i]);
+    }
+  }
+  std::vector<double2> beams;
+  beams.reserve(rc / step + 1);
+  fs->slot_of.clear();
+  fs->n_valid = 0;
+  fs->n_always_off = 0;
+  int slot = 0;
+  const double res = e->map.resolution;
+  for (int i = 0; i < rc; i += step, ++slot)
+  {
+    const double r = ranges[i];
+    if (r >= range_max)
+      continue;
+    if (r != r)
+      continue;
+    ++fs->n_valid;
+    if (keep_slot && !(slot < (int)keep_slot->size() && (*keep_slot)[slot]))
+      continue;
+    double2 b;
+    b.x = (r * e->trig_cos[i]) / res;
+    b.y = (r * e->trig_sin[i]) / res;
+    // a non-finite or absurdly long beam (> 2^28 cells) ends off the map for every pose in the
+    // reference ((int) of a NaN or huge double is INT_MIN on x86): it is not staged, its constant
+    // off-map term is added in the epilogue instead
+    if (!(std::fabs(b.x) < 268435456.0 && std::fabs(b.y) < 268435456.0))
+    {
+      ++fs->n_always_off;
+      continue;
+    }
+    beams.push_back(b);
+    fs->slot_of.push_back(slot);
+  }
+  fs->n_slots = slot;
+  fs->n_staged = (int)beams.size();
+  if (fs->n_staged > kMaxBeams)
+    return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
+  fs->beams_off = 0;
+  fs->table_off = ((size_t)fs->n_staged * sizeof(double2) + 255) & ~(size_t)255;
+  fs->bytes = fs->table_off + (size_t)fs->table_len * sizeof(double);
+  ScanSlot* s;
+  int rcode = acquire_slot(e, fs->bytes, &s);
+  if (rcode != BPF_OK)
+    return rcode;
+  std::memcpy(s->host.p + fs->beams_off, beams.data(), beams.size() * sizeof(double2));
+  double* table = reinterpret_cast<double*>(s->host.p + fs->table_off);
+  bpf_engine::TermKey key;
+  key.model = pm.model;
+  key.map_version = e->map_version;
+  key.z_hit = pm.z_hit;
+  key.z_rand = pm.z_rand;
+  key.sigma = pm.sigma_hit;
+  key.range_max = range_max;
+  const bool table_cached = key == e->term_key && (int)e->term_table.size() == K + 1;
+  const double denom = 2 * pm.sigma_hit * pm.sigma_hit;
+  const double rand_mult = 1.0 / range_max;
+  for (int k = 0; k <= K && !table_cached; ++k)
+  {
+    const bool off_map = (k == K);
+    const double z = off_map ? e->map.max_dist : (double)e->h_levels[k];
+    double pz = 0.0;
+    if (pm.model == BPF_MODEL_LIKELIHOOD_FIELD)
+    {
+      pz += pm.z_hit * std::exp(-(z * z) / denom);
+      pz += pm.z_rand * rand_mult;
+      table[k] = pz * pz * pz;
+    }
+    else if (pm.model == BPF_MODEL_LIKELIHOOD_FIELD_GOMPERTZ)
+    {
+      pz += pm.z_hit * std::exp(-(z * z) / denom);
+      pz += pm.z_rand;
+      table[k] = pz;
+    }
+    else
+    {
+      if (off_map)
+      {
+        const double max_dist_prob = std::exp(-(e->map.max_dist * e->map.max_dist) / denom);
+        pz += pm.z_hit * max_dist_prob;
+      }
+      else
+        pz += pm.z_hit * std::exp(-(z * z) / denom);
+      pz += pm.z_rand * rand_mult;
+      table[k] = std::log(pz);
+    }
+  }
+  if (table_cached)
+    std::memcpy(table, e->term_table.data(), (size_t)(K + 1) * sizeof(double));
+  else
+  {
+    e->term_table.assign(table, table + K + 1);
+    e->term_key = key;
+  }
+  fs->off_map_term = table[K];
+  // the copy to the device slot is done by k_field_prep (launch_field) unless the staging block is
+  // larger than what its grid covers
+  fs->copy_pending = true;
+  *slot_out = s;
+  return BPF_OK;
+}
+
+int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldScan& fs, int* obs_count,
+                 int skip_level, bool want_partials = false)
+{
+  FieldScoreArgs A{};
+  A.p = p;
+  A.n = n;
+  A.beams = reinterpret_cast<const double2*>(s->dev.p + fs.beams_off);
+  A.n_beams = fs.n_staged;
+  A.table = reinterpret_cast<const double*>(s->dev.p + fs.table_off);
+  A.table_len = fs.table_len;
+  A.map = e->map;
+  A.sp_x = e->pm.pose[0];
+  A.sp_y = e->pm.pose[1];
+  A.sp_th = e->pm.pose[2];
+  A.off_map_factor = e->pm.off_map_factor;
+  A.non_free_factor = e->pm.non_free_factor;
+  A.non_free_radius = e->pm.non_free_radius;
+  A.model = e->pm.model;
+  A.g = e->pm.g;
+  A.n_valid = fs.n_valid;
+  A.obs_count = obs_count;
+  A.skip_level = skip_level;
+  A.extra_term = 0.0;
+  for (int k = 0; k < fs.n_always_off; ++k)
+    A.extra_term += fs.off_map_term;
+  const bool count_only = obs_count != nullptr;
+  const bool table_lds = !count_only && fs.table_len <= kTableLdsMax;
+  const size_t table_bytes = table_lds ? (((size_t)fs.table_len * sizeof(double) + 15) & ~(size_t)15) : 0;
+  // at least the four block partials that reuse the head of the block (kernels_score.hpp)
+  const size_t lds = std::max<size_t>(32, (size_t)fs.n_staged * sizeof(double2) + table_bytes);
+  // per-particle scanner pose / trig once per update (shared by both scoring forms)
+  const int prep_blocks = blocks_for(n, 256);
+  HIPCHK(e, e->d_prep.reserve((size_t)n));
+  HIPCHK(e, e->d_prep_stats.reserve((size_t)prep_blocks * kPrepStats));
+  {
+    const int n16 = (int)((fs.bytes + 15) / 16);
+    const bool ride = fs.copy_pending && n16 <= prep_blocks * 256;
+    if (fs.copy_pending && !ride)
+      HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs.bytes, hipMemcpyHostToDevice, e->stream));
+    ProfScope pa(e, BPF_K_SCORE_AUX);
+    const uint4* src = ride ? reinterpret_cast<const uint4*>(s->host.p) : static_cast<const uint4*>(nullptr);
+    if (e->window_enabled)
+      hipLaunchKernelGGL(k_field_prep<true>, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
+                         A.sp_th, e->d_prep.p, e->d_prep_stats.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
+    else
+      hipLaunchKernelGGL(k_field_prep<false>, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
+                         A.sp_th, e->d_prep.p, e->d_prep_stats.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
+  }
+  A.prep = e->d_prep.p;
+  // One resident round: blocks per CU = what registers, LDS and the SGPR rule admit (the occupancy
+  // API can over-report by one block for SGPR-heavy kernels: MI355X_MICROARCH.md, residency).
+  int api_blocks = 0;
+  const void* kfn = count_only ? reinterpret_cast<const void*>(&k_score_field<true, false>)
+                               : (table_lds ? reinterpret_cast<const void*>(&k_score_field<false, true>)
+                                            : reinterpret_cast<const void*>(&k_score_field<false, false>));
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, kfn, 256, lds) != hipSuccess || api_blocks < 1)
+    api_blocks = 1;
+  const int per_cu = std::max(1, std::min(api_blocks, 6));
+  const int resident_waves = e->n_cu * per_cu * 4;
+  A.per_wave = std::max(1, blocks_for(n, resident_waves));
+  const int grid = std::max(1, blocks_for(blocks_for(n, A.per_wave), 4));
+  A.block_partials = nullptr;
+  A.skip_if_set = nullptr;
+  e->last_used_window_path = false;
+  if (want_partials && !count_only)
+  {
+    HIPCHK(e, e->d_block_partials.reserve((size_t)grid));
+    A.block_partials = e->d_block_partials.p;
+    e->fused_partials = grid;
+    // LDS-window path for big updates: the device decides (from the cloud's spread) whether the
+    // window kernels or k_score_field do the work; the other one returns immediately.
+    const int n_chunks = (fs.n_staged + 63) / 64;
+    const size_t win_lds = (size_t)kWinDim * kWinDim * sizeof(uint16_t) + ((size_t)fs.table_len + 1) * 8 + 64 * 16;
+    if (e->window_enabled && n >= 16384 && fs.n_staged >= 64 && n_chunks <= kMaxChunks && table_lds &&
+        fs.table_len <= 2047 && win_lds <= 160 * 1024)
+    {
+      HIPCHK(e, e->d_chunk_partials.reserve((size_t)n_chunks * n));
+      HIPCHK(e, e->d_plan.reserve(1));
+      if (!e->window_lds_attr_set)
+      {
+        HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_window),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e->window_lds_attr_set = true;
+      }
+      {
+        ProfScope pa(e, BPF_K_SCORE_AUX);
+        hipLaunchKernelGGL(k_field_windows, dim3(1), dim3(1024), 0, e->stream, e->d_prep_stats.p, prep_blocks,
+                           A.beams, fs.n_staged, e->map, e->d_plan.p);
+      }
+      WindowScoreArgs W{};
+      W.n = n;
+      W.prep = e->d_prep.p;
+      W.beams = A.beams;
+      W.n_beams = fs.n_staged;
+      W.table = A.table;
+      W.table_len = fs.table_len;
+      W.map = e->map;
+      W.plan = e->d_plan.p;
+      W.partials = e->d_chunk_partials.p;
+      W.slabs = std::max(1, e->n_cu / n_chunks);
+      {
+        ProfScope pw(e, BPF_K_SCORE_WINDOW);
+        hipLaunchKernelGGL(k_score_window, dim3(n_chunks, W.slabs), dim3(kWinThreads), win_lds, e->stream, W);
+      }
+      FieldFinishArgs F{};
+      F.p = p;
+      F.n = n;
+      F.partials = e->d_chunk_partials.p;
+      F.plan = e->d_plan.p;
+      F.map = e->map;
+      F.off_map_factor = A.off_map_factor;
+      F.non_free_factor = A.non_free_factor;
+      F.non_free_radius = A.non_free_radius;
+      F.model = A.model;
+      F.g = A.g;
+      F.n_valid = A.n_valid;
+      F.extra_term = A.extra_term;
+      F.block_partials = A.block_partials;
+      {
+        ProfScope pa(e, BPF_K_SCORE_AUX);
+        hipLaunchKernelGGL(k_field_finish, dim3(grid), dim3(256), 0, e->stream, F);
+      }
+      HIPCHK(e, hipGetLastError());
+      A.skip_if_set = &e->d_plan.p->use_window;
+      e->last_used_window_path = true;
+    }
+  }
+  ProfScope ps(e, BPF_K_SCORE);
+  if (count_only)
+    hipLaunchKernelGGL((k_score_field<true, false>), dim3(grid), dim3(256), lds, e->stream, A);
+  else if (table_lds)
+    hipLaunchKernelGGL((k_score_field<false, true>), dim3(grid), dim3(256), lds, e->stream, A);
+  else
+    hipLaunchKernelGGL((k_score_field<false, false>), dim3(grid), dim3(256), lds, e->stream, A);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+int sum_into_slot(bpf_engine* e, const double* v, int n, int slot, int update_averages, int n_samples)
+{
+  const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+  HIPCHK(e, e->d_partials.reserve((size_t)nb));
+  ProfScope ps(e, BPF_K_REDUCE);
+  hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, v, n, e->d_partials.p);
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_partials.p, nb, e->d_scalars.p,
+                     slot, update_averages, n_samples, e->alpha_slow, e->alpha_fast);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+int ensure_scalars(bpf_engine* e)
+{
+  if (e->d_scalars.p)
+    return BPF_OK;
+  HIPCHK(e, e->d_scalars.reserve(1));
+  HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
+  HIPCHK(e, e->h_scalars.reserve(1));
+  HIPCHK(e, e->d_flags.reserve(8));
+  HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, 8 * sizeof(int), e->stream));
+  HIPCHK(e, e->h_flags.reserve(8));
+  HIPCHK(e, e->h_done.reserve(16));
+  e->h_done.p[0] = 0;
+  e->zero_copy_keys = getenv("BPF_NO_ZEROCOPY") == nullptr;
+  return BPF_OK;
+}
+
+// Second half of beam skipping: mask from the (possibly shard-summed) counts in d_obs_count over
+// `n_total` particles, then pass 2 over this engine's `n` particles.
+int score_planar_beamskip_finish(bpf_engine* e, ParticlesDev p, int n, long long n_total, const double* ranges,
+                                 const double* angles, int rc, double range_max, bool* forced_zero, bool want_partials)
+{
+  const PlanarModel& pm = e->pm;
+  const FieldScan& fs = e->skip_fs;
+  e->skip_pending = false;
+  const int nv = std::max(fs.n_staged, 1);
+  std::vector<int> counts((size_t)nv, 0);
+  HIPCHK(e, hipMemcpyAsync(counts.data(), e->d_obs_count.p, (size_t)fs.n_staged * sizeof(int), hipMemcpyDeviceToHost,
+                           e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  std::vector<int> obs_count((size_t)pm.max_beams, 0);
+  for (int v = 0; v < fs.n_staged; ++v)
+    if (fs.slot_of[v] < pm.max_beams)
+      obs_count[fs.slot_of[v]] = counts[v];
+  std::vector<uint8_t> mask_slot((size_t)pm.max_beams, 0);
+  int skipped = 0;
+  for (int b = 0; b < pm.max_beams; ++b)
+  {
+    if ((obs_count[b] / (double)n_total) > pm.beam_skip_threshold)
+      mask_slot[b] = 1;
+    else
+      skipped++;
+  }
+  const bool error = skipped >= (pm.max_beams * pm.beam_skip_error_threshold);
+  // A kept slot that was never written holds 0.0 in the reference's scratch matrix, and
+  // log(0) = -inf zeroes every weight (planar_scanner.cpp:519-527).
+  std::vector<uint8_t> visited((size_t)pm.max_beams, 0);
+  for (int v = 0; v < fs.n_staged; ++v)
+    if (fs.slot_of[v] < pm.max_beams)
+      visited[fs.slot_of[v]] = 1;
+  bool poisoned = false;
+  for (int b = 0; b < pm.max_beams; ++b)
+    if ((error || mask_slot[b]) && !visited[b])
+      poisoned = true;
+  if (poisoned)
+  {
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, p.w, 0.0, n);
+    HIPCHK(e, hipGetLastError());
+    *forced_zero = true;
+    return BPF_OK;
+  }
+  // pass 2: stage only the kept beams (all of them when the error switch tripped) and score
+  std::vector<uint8_t> keep((size_t)std::max(fs.n_slots, pm.max_beams), 0);
+  for (size_t b = 0; b < keep.size(); ++b)
+    keep[b] = error ? 1 : ((int)b < pm.max_beams ? mask_slot[b] : 0);
+  ScanSlot* s2 = nullptr;
+  FieldScan fs2;
+  int rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s2, &fs2, &keep);
+  if (rcode != BPF_OK)
+    return rcode;
+  rcode = launch_field(e, p, n, s2, fs2, nullptr, 0, want_partials);
+  if (rcode != BPF_OK)
+    return rcode;
+  return release_slot(e, s2);
+}
+
+// Scores `n` particles of `p` with the configured planar model (+ recalcWeight).  Leaves the
+// weights un-normalised.  set_converged feeds the prob model's beam-skip switch.  defer_beamskip_pass2: stop
+// after the counting pass of beam skipping (e->skip_pending is then set) so that a sharded driver can sum the
+// counts over the shards before score_planar_beamskip_finish.
+int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const double* ranges,
+                 const double* angles, int rc, double range_max, bool* forced_zero, bool want_partials = false,
+                 bool defer_beamskip_pass2 = false)
+{
+  *forced_zero = false;
+  e->fused_partials = 0;
+  e->tile_sums_n = -1;
+  if (!e->have_map)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
+  if (!e->have_lut)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "distance LUT missing (reference: isMapInitialized, node_2d.cpp:406-410)");
+  if (!e->pm.configured)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "planar model not set");
+  if (rc <= 0 || ranges == nullptr || angles == nullptr || n <= 0)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "empty scan or sample set");
+  const PlanarModel& pm = e->pm;
+  e->evals_last = 0;
+
+  if (pm.model == BPF_MODEL_BEAM)
+  {
+    const int step = (rc - 1) / (pm.max_beams - 1);  // planar_scanner.cpp:193, not clamped
+    if (step < 1)
+      return e->fail(BPF_ERR_BEAM_STEP, "beam model: range_count < max_beams makes the reference loop forever");
+    std::vector<BeamRec> beams;
+    for (int i = 0; i < rc; i += step)
+    {
+      BeamRec b;
+      b.cb = std::cos(angles[i]);
+      b.sb = std::sin(angles[i]);
+      b.obs = ranges[i];
+      b.short_t = pm.z_short * pm.lambda_short * std::exp(-pm.lambda_short * ranges[i]);
+      b.tail_t = 0.0;
+      if (ranges[i] == range_max)
+        b.tail_t = pm.z_max * 1.0;
+      if (ranges[i] < range_max)
+        b.tail_t = pm.z_rand * 1.0 / range_max;
+      beams.push_back(b);
+    }
+    if ((int)beams.size() > kMaxBeams)
+      return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
+    // Rays of similar length walk together: order the beams by observed range so that the 64 lanes
+    // of one iteration finish their Bresenham walks at about the same step (the per-particle sum is
+    // order-independent up to rounding).  NaN ranges sort last.
+    std::stable_sort(beams.begin(), beams.end(), [](const BeamRec& a, const BeamRec& b) {
+      const bool an = a.obs != a.obs, bn = b.obs != b.obs;
+      if (an || bn)
+        return !an && bn;
+      return a.obs > b.obs;
+    });
+    const size_t bytes = beams.size() * sizeof(BeamRec);
+    ScanSlot* s;
+    int rcode = acquire_slot(e, bytes, &s);
+    if (rcode != BPF_OK)
+      return rcode;
+    std::memcpy(s->host.p, beams.data(), bytes);
+    HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, bytes, hipMemcpyHostToDevice, e->stream));
+    BeamModelArgs A{};
+    A.p = p;
+    A.n = n;
+    A.beams = reinterpret_cast<const BeamRec*>(s->dev.p);
+    A.n_beams = (int)beams.size();
+    A.map = e->map;
+    A.sp_x = pm.pose[0];
+    A.sp_y = pm.pose[1];
+    A.sp_th = pm.pose[2];
+    A.off_map_factor = pm.off_map_factor;
+    A.non_free_factor = pm.non_free_factor;
+    A.non_free_radius = pm.non_free_radius;
+    A.range_max = range_max;
+    A.z_hit = pm.z_hit;
+    A.denom = 2 * pm.sigma_hit * pm.sigma_hit;
+    A.cells_walked = nullptr;
+    if (e->count_cells)
+    {
+      if (!e->d_cells_walked.p)
+      {
+        HIPCHK(e, e->d_cells_walked.reserve(1));
+        HIPCHK(e, hipMemsetAsync(e->d_cells_walked.p, 0, sizeof(unsigned long long), e->stream));
+      }
+      A.cells_walked = e->d_cells_walked.p;
+    }
+    int api_blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, reinterpret_cast<const void*>(&k_score_beam), 256,
+                                                     bytes) != hipSuccess || api_blocks < 1)
+      api_blocks = 1;
+    const int per_cu = std::max(1, std::min(api_blocks, 6));
+    // rays differ in length, so cut the set ~4x finer than one range per resident wave
+    A.per_wave = std::max(1, blocks_for(n, e->n_cu * per_cu * 4 * 4));
+    const int grid = std::max(1, blocks_for(blocks_for(n, A.per_wave), 4));
+    A.block_partials = nullptr;
+    if (want_partials)
+    {
+      HIPCHK(e, e->d_block_partials.reserve((size_t)grid));
+      A.block_partials = e->d_block_partials.p;
+      e->fused_partials = grid;
+    }
+    {
+      ProfScope ps(e, BPF_K_SCORE);
+      hipLaunchKernelGGL(k_score_beam, dim3(grid), dim3(256), bytes, e->stream, A);
+    }
+    HIPCHK(e, hipGetLastError());
+    e->evals_last = (long long)n * (long long)beams.size();
+    return release_slot(e, s);
+  }
+
+  ScanSlot* s = nullptr;
+  FieldScan fs;
+  int rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s, &fs);
+  if (rcode != BPF_OK)
+    return rcode;
+  e->evals_last = (long long)n * fs.n_valid;
+
+  const bool beamskip = pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && pm.do_beamskip && set_converged;
+  if (!beamskip)
+  {
+    rcode = launch_field(e, p, n, s, fs, nullptr, 0, want_partials);
+    if (rcode != BPF_OK)
+      return rcode;
+    return release_slot(e, s);
+  }
+
+  // Beam skipping (planar_scanner.cpp:352-395,482-529): pass 1 counts, per beam, the particles
+  // whose end point lies within beam_skip_distance of an obstacle; the host forms the mask;
+  // pass 2 integrates the kept beams.  (The reference stores every pz in an N x max_beams
+  // scratch matrix between the passes; re-evaluating is cheaper than 8 B x N x beams of HBM.)
+  const int nv = std::max(fs.n_staged, 1);
+  HIPCHK(e, e->d_obs_count.reserve((size_t)nv));
+  HIPCHK(e, hipMemsetAsync(e->d_obs_count.p, 0, (size_t)nv * sizeof(int), e->stream));
+  int skip_level = 0;  // levels are ascending: z < d  <=>  level index < first level >= d
+  while (skip_level < e->map.n_levels && (double)e->h_levels[skip_level] < pm.beam_skip_distance)
+    ++skip_level;
+  rcode = launch_field(e, p, n, s, fs, e->d_obs_count.p, skip_level);
+  if (rcode != BPF_OK)
+    return rcode;
+  rcode = release_slot(e, s);
+  if (rcode != BPF_OK)
+    return rcode;
+  e->skip_fs = fs;
+  e->skip_pending = true;
+  if (defer_beamskip_pass2)
+    return BPF_OK;  // sharded: the per-beam counts are summed over the shards first
+  return score_planar_beamskip_finish(e, p, n, n, ranges, angles, rc, range_max, forced_zero, want_partials);
+}

@@ -52,7 +52,7 @@ def test_product_code_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "badger_amcl_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".hpp", ".inl", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "amcl_oracle" not in text, f
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
