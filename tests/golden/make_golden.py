@@ -43,6 +43,57 @@ def main():
             resampled=opf.samples[:out.sample_count], sample_count=out.sample_count, leaf_count=out.leaf_count,
             bin_count=out.node_count, rng_after=np.uint64(opf.pf.rng), converged=out.converged)
         print(model, "M", out.sample_count, "leaf", out.leaf_count)
+    for resampler in (0, 1):
+        make_cycle(orc, Scenario, resampler)
+
+
+CYCLE_ALPHA = (0.001, 0.1)                                   # the node's default decay rates
+CYCLE_ODOM = (2, (0.05, 0.04, 0.03, 0.02, 0.01))             # diff-corrected
+CYCLE_ODATA = ((1.0, 2.0, 0.3), (0.03, -0.01, 0.02), (0.03, 0.01, 0.02))
+
+
+def cycle_scans(sc):
+    return [sc.ranges, np.clip(sc.ranges * 0.6, 0.05, 29.0)]
+
+
+def run_cycle(orc, sc, resampler):
+    """Two full cycles motion -> sensor -> resample (the second with w_diff > 0: random free-space poses) and
+    the cluster statistics of the final set, on the oracle."""
+    n = sc.samples.shape[0]
+    opf = orc.ParticleFilter(50, n, CYCLE_ALPHA[0], CYCLE_ALPHA[1], 85.0, seed=77)
+    opf.set_resample_model(resampler)
+    opf.set_samples(sc.samples)
+    opf.set_random_pose_source(sc.omap, sc.map_factors[2])
+    p = sc.oracle_planar(61, "lf")
+    rec = {}
+    for c, ranges in enumerate(cycle_scans(sc)):
+        cur = opf.samples[:opf.sample_count]
+        opf.pf.rng = orc.odom_update_action(CYCLE_ODOM[0], CYCLE_ODOM[1], *CYCLE_ODATA, cur, opf.pf.rng)
+        rec["moved%d" % c] = cur.copy()
+        opf.update_sensor(lambda s, conv: orc.planar_apply(p, sc.omap, s, ranges, sc.angles, sc.range_max, conv))
+        rec["weights%d" % c] = opf.samples[:opf.sample_count, 3].copy()
+        out = opf.update_resample()
+        M = out.sample_count
+        rec["resampled%d" % c] = opf.samples[:M].copy()
+        rec["scalars%d" % c] = np.array([M, out.leaf_count, out.node_count, out.cluster_count, out.converged],
+                                        dtype=np.int64)
+        rec["w_diff%d" % c] = out.w_diff
+        rec["rng%d" % c] = np.uint64(opf.pf.rng)
+        rec["mean%d" % c] = np.array(out.mean[:])
+        rec["cov%d" % c] = np.array(list(out.cov[:]) + [out.cov_theta])
+    return rec
+
+
+def make_cycle(orc, Scenario, resampler):
+    sc = Scenario(orc, size=120, n=600, beams=61, cloud="mixture", max_dist=1.0, seed=23)
+    rec = run_cycle(orc, sc, resampler)
+    assert rec["w_diff1"] > 0.01
+    np.savez_compressed(os.path.join(HERE, "cycle_%s.npz" % ("multinomial", "systematic")[resampler]),
+                        cells=sc.cells.astype(np.int8), origin=np.array(sc.origin, dtype=np.float32), lut=sc.lut,
+                        max_dist=sc.max_dist, ranges=sc.ranges, angles=sc.angles, range_max=sc.range_max,
+                        samples=sc.samples, scanner_pose=np.array(sc.scanner_pose),
+                        map_factors=np.array(sc.map_factors), **rec)
+    print("cycle", resampler, "M", rec["scalars0"][0], rec["scalars1"][0], "w_diff", rec["w_diff1"])
 
 
 if __name__ == "__main__":
