@@ -98,3 +98,16 @@ const char* bpf_score_kernel_name(const bpf_engine* e)
     return "k_score_beam";
   return "k_score_field";
 }
+
+#ifdef BPF_PHASE_TIMING
+// diagnostic builds only (not in badger_pf.h): rows of the last k_score_field launch, see tools/phase_timing.py
+int bpf_debug_phase_cycles(unsigned long long* out, int n_waves)
+{
+  if (n_waves > kPhaseWaves)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), (size_t)n_waves * 8 * sizeof(unsigned long long)) !=
+      hipSuccess)
+    return BPF_ERR_HIP;
+  return BPF_OK;
+}
+#endif

@@ -554,6 +554,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->count_cells = value != 0;
   else if (option == BPF_OPT_KLD_DEVICE_MIN)
     e->kld_device_min = value > 0 ? value : 0x7fffffff;
+  else if (option == BPF_OPT_GRADED_SHARES)
+    e->graded_shares = value != 0;
   else
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown option");
   return BPF_OK;

@@ -63,6 +63,11 @@ struct FieldScoreArgs
   double off_map_factor, non_free_factor, non_free_radius;
   double extra_term;         // sum of the terms of beams that are off the map for every pose
   int per_wave;              // particles owned by each wave (static partition)
+  // graded partition (share_count[0] > 0): the waves of block b own share_count[r] particles each, r = b /
+  // blocks_per_round, starting at share_base[r] + ((b % blocks_per_round) * 4 + wave) * share_count[r]
+  int share_count[8];
+  int share_base[8];
+  int blocks_per_round;
   int model;
   GompertzDev g;
   int n_valid;               // beams that count towards the Gompertz mean

@@ -176,6 +176,7 @@ struct bpf_engine
   DevBuf<WindowPlan> d_plan;
   bool window_lds_attr_set = false;
   bool beam_lds_attr_set = false;
+  bool graded_shares = true;    // BPF_OPT_GRADED_SHARES
   bool window_enabled = false;  // measured: no gain on wide clouds; opt-in via BPF_OPT_WINDOW_PATH
   bool last_used_window_path = false;
   DevBuf<unsigned long long> d_cells_walked;

@@ -209,7 +209,26 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   const int per_cu = std::max(1, std::min(api_blocks, 6));
   const int resident_waves = e->n_cu * per_cu * 4;
   A.per_wave = std::max(1, blocks_for(n, resident_waves));
-  const int grid = std::max(1, blocks_for(blocks_for(n, A.per_wave), 4));
+  int grid = std::max(1, blocks_for(blocks_for(n, A.per_wave), 4));
+  for (int k = 0; k < 8; ++k)
+    A.share_count[k] = A.share_base[k] = 0;
+  A.blocks_per_round = e->n_cu;
+  if (e->graded_shares && !count_only && per_cu == 4 && n >= e->n_cu * 4 * 64)
+  {
+    // graded partition (see k_score_field): the share of a wave by the placement round of its block.  The shares
+    // were measured on MI355X at 4 blocks per CU (tools/phase_timing.py): 40 / 28 / 19 / 13 % of a SIMD's particles
+    // make every wave end within a few microseconds of the others (equal shares: 46 .. 86 us).
+    static const double kShare[4] = { 0.40, 0.28, 0.19, 0.13 };
+    const double per_simd = (double)n / (e->n_cu * 4);
+    int base = 0;
+    for (int k = 0; k < 4; ++k)
+    {
+      A.share_count[k] = std::max(1, (int)std::ceil(per_simd * kShare[k]));
+      A.share_base[k] = base;
+      base += A.share_count[k] * e->n_cu * 4;
+    }
+    grid = e->n_cu * per_cu;
+  }
   A.block_partials = nullptr;
   A.skip_if_set = nullptr;
   e->last_used_window_path = false;

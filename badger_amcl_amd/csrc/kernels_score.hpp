@@ -172,9 +172,30 @@ constexpr int kFieldUnroll = BPF_FIELD_UNROLL;
 #ifndef BPF_FIELD_WAVES
 #define BPF_FIELD_WAVES 4
 #endif
+#ifdef BPF_PHASE_TIMING
+// diagnostic builds only (tools/phase_timing.py): per-wave, per-phase core-clock totals (s_memtime) and the wave's
+// start / end on the constant 100 MHz clock (s_memrealtime); one private row per wave, no atomics
+constexpr int kPhaseWaves = 8192;
+__device__ unsigned long long g_phase_cycles[kPhaseWaves][8];
+#define PHASE_MARK(idx)                            \
+  do                                               \
+  {                                                \
+    const long long _now = clock64();              \
+    _ph[idx] += (unsigned long long)(_now - _t);   \
+    _t = _now;                                     \
+  } while (0)
+#else
+#define PHASE_MARK(idx)
+#endif
+
 template <bool COUNT_ONLY, bool TABLE_IN_LDS>
 __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const FieldScoreArgs A)
 {
+#ifdef BPF_PHASE_TIMING
+  unsigned long long _ph[6] = { 0, 0, 0, 0, 0, 0 };
+  long long _t = clock64();
+  const long long _w0 = wall_clock64();
+#endif
   if (A.skip_if_set != nullptr && *A.skip_if_set != 0)
     return;  // kernels_window.hpp handles this update
   extern __shared__ __align__(16) unsigned char smem[];
@@ -191,6 +212,7 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  PHASE_MARK(0);  // LDS staging + barrier
   const MapDev& M = A.map;
   const char* table_b = reinterpret_cast<const char*>(TABLE_IN_LDS ? s_table : A.table);
   const char* __restrict__ tiles = reinterpret_cast<const char*>(M.lut_tiles);
@@ -201,7 +223,19 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
   // contiguous range of per_wave particles (a grid with a few blocks more than fit would run a
   // second round for them and double the kernel time).  The range is walked 16 particles at a time.
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
-  const int p_begin = min(A.n, wid * A.per_wave), p_end = min(A.n, p_begin + A.per_wave);
+  int p_begin = min(A.n, wid * A.per_wave), p_end = min(A.n, p_begin + A.per_wave);
+  if (A.share_count[0] > 0)
+  {
+    // Graded partition.  All blocks of the one resident round start together, and the SIMD's issue arbiter
+    // favours its oldest wave: with equal shares the waves of the block placed first on a CU finish at 46 us,
+    // those of the fourth at 86 us, and the SIMD idles more and more towards the end.  Blocks are placed in
+    // blockIdx order, n_cu per round, so the round a block belongs to tells its age rank on its CU and the
+    // shares are graded by it (tools/phase_timing.py shows the effect: every wave then ends within 70-80 us).
+    const int round = min((int)blockIdx.x / A.blocks_per_round, 7);
+    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - round * A.blocks_per_round) * 4 + wave);
+    p_begin = min(A.n, A.share_base[round] + slot * A.share_count[round]);
+    p_end = min(A.n, p_begin + A.share_count[round]);
+  }
   for (int base = p_begin; base < p_end; base += 16)
   {
     const int cnt = min(16, p_end - base);
@@ -242,6 +276,7 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
           }
         }
       }
+      PHASE_MARK(1);  // group start + full beam batches
       for (; b < n_beams; b += 64)
       {
         const double2 B1 = s_beams[b];
@@ -257,6 +292,7 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
           }
         }
       }
+      PHASE_MARK(2);  // remainder loop
       // transposed reduction: 16 per-particle partials x 64 lanes -> lane k (k < 16) holds particle k's sum.
       // Step h: lanes exchange the half of their values they do not keep (xor 32, 16, 8, 4 halve the
       // value count 16 -> 1), then two plain butterfly steps finish (xor 2, 1).
@@ -302,6 +338,7 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
         mine = __shfl(v1, src_lane, 64);  // lane k (< 16) reads a lane whose owner is k
         (void)owner;
       }
+      PHASE_MARK(3);  // transposed reduction
     }
     else
     {
@@ -345,6 +382,7 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
       A.p.w[i] = w;
       wsum += w;
     }
+    PHASE_MARK(4);  // epilogue
   }
   if (!COUNT_ONLY && A.block_partials != nullptr)
   {
@@ -361,6 +399,20 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
     if (tid == 0)
       A.block_partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
   }
+  PHASE_MARK(5);  // block partial
+#ifdef BPF_PHASE_TIMING
+  if (lane == 0)
+  {
+    const int _w = blockIdx.x * 4 + wave;
+    if (_w < kPhaseWaves)
+    {
+      for (int q = 0; q < 6; ++q)
+        g_phase_cycles[_w][q] = _ph[q];
+      g_phase_cycles[_w][6] = (unsigned long long)_w0;
+      g_phase_cycles[_w][7] = (unsigned long long)wall_clock64();
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -180,8 +180,11 @@ enum
   BPF_OPT_CDF_SERIAL = 0,
   BPF_OPT_COUNT_CELLS = 1,
   BPF_OPT_WINDOW_PATH = 2,  /* default 0: 1 allows the LDS-window scoring kernels (device-side switch) */
-  BPF_OPT_KLD_DEVICE_MIN = 3 /* default 8192: candidate draws left after the first window from which the KLD stop
-                              * rule (ordered kd-tree replay) runs on the device instead of the host; 0 = never */
+  BPF_OPT_KLD_DEVICE_MIN = 3, /* default 8192: candidate draws left after the first window from which the KLD stop
+                               * rule (ordered kd-tree replay) runs on the device instead of the host; 0 = never */
+  BPF_OPT_GRADED_SHARES = 4   /* default 1: the scoring kernel's waves own particle shares graded by the placement
+                               * round of their block; 0 = equal shares.  Results do not
+                               * depend on it beyond the summation order of the weight total. */
 };
 int bpf_set_option(bpf_engine* e, int option, int value);
 /* cells visited by calcRange walks since the last reset (BPF_OPT_COUNT_CELLS) */
