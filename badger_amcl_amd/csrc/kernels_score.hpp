@@ -204,10 +204,30 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
   double2* s_beams = reinterpret_cast<double2*>(smem + (((size_t)table_lds_len * sizeof(double) + 15) & ~(size_t)15));
 
   const int tid = threadIdx.x;
-  for (int i = tid; i < A.n_beams; i += 256)
-    s_beams[i] = A.beams[i];
-  for (int i = tid; i < table_lds_len; i += 256)
-    s_table[i] = A.table[i];
+  // staging: all of a thread's loads are issued before the first LDS store, so their latencies overlap
+  // (a plain copy loop waits for every load in turn: ~8 round trips with 1000 blocks asking at once)
+  for (int i0 = 0; i0 < A.n_beams; i0 += 4 * 256)
+  {
+    double2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v[q] = A.beams[min(i0 + q * 256 + tid, A.n_beams - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * 256 + tid < A.n_beams)
+        s_beams[i0 + q * 256 + tid] = v[q];
+  }
+  for (int i0 = 0; i0 < table_lds_len; i0 += 4 * 256)
+  {
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v[q] = A.table[min(i0 + q * 256 + tid, table_lds_len - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * 256 + tid < table_lds_len)
+        s_table[i0 + q * 256 + tid] = v[q];
+  }
   __syncthreads();
 
   const int lane = tid & 63;
