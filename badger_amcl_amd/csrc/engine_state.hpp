@@ -222,6 +222,8 @@ struct bpf_engine
   bool count_cells = false;
   KdHistogram hist;
   SeenKeys seen;
+  DevBuf<int> d_cdf_guide;     // head start for the CDF bisection (k_scan_final / cdf_find_guided)
+  bool cdf_guide_valid = false;
   DevBuf<double> d_cdf, d_partials, d_targets, d_block_partials, d_tile_sums;
   int fused_partials = 0;     // > 0: the last scoring launch left that many per-block weight partials
   int tile_sums_n = -1;       // >= 0: d_tile_sums holds the 2048-tile sums of the current weights for that n

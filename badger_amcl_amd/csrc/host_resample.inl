@@ -19,6 +19,12 @@ int fetch_scalars(bpf_engine* e)
 int build_cdf(bpf_engine* e, const double* w, int n)
 {
   HIPCHK(e, e->d_cdf.reserve((size_t)n + 1));
+  if (!e->d_cdf_guide.p)
+  {
+    HIPCHK(e, e->d_cdf_guide.reserve(kCdfGuide + 2));
+    HIPCHK(e, hipMemsetAsync(e->d_cdf_guide.p, 0xFF, (kCdfGuide + 2) * sizeof(int), e->stream));  // "no entry"
+  }
+  e->cdf_guide_valid = !e->cdf_serial;
   ProfScope ps(e, BPF_K_CDF);
   if (e->cdf_serial)
   {
@@ -44,13 +50,13 @@ int build_cdf(bpf_engine* e, const double* w, int n)
     {
       // few tiles: every block of the final pass forms its own offset (one launch less)
       hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 0, e->d_cdf.p,
-                         e->d_flags.p);
+                         e->d_flags.p, e->d_cdf_guide.p);
     }
     else
     {
       hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, tiles, nb, e->d_flags.p);
       hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 1, e->d_cdf.p,
-                         nullptr);
+                         nullptr, e->d_cdf_guide.p);
     }
   }
   HIPCHK(e, hipGetLastError());
@@ -343,6 +349,7 @@ int resample_multinomial(bpf_engine* e, double w_diff)
     A.sharded = 0;
     A.chain = chain;
     A.free_space = free_space;
+    A.guide = e->cdf_guide_valid ? e->d_cdf_guide.p : nullptr;
     // long stream ahead: either the first window found no stop, or the previous cycle ran to the end
     const bool long_stream = (m0 > 0 || e->window_hint >= maxs) && maxs - m0 >= e->kld_device_min;
     if (long_stream && !device_declined)

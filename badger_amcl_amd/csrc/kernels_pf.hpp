@@ -8,6 +8,8 @@
 namespace bpf
 {
 
+constexpr int kCdfGuide = 1024;  // CDF guide table: entries 0 .. kCdfGuide (k_scan_final, cdf_find_guided)
+
 // ------------------------------------------------------------------ layout conversion
 // PFSample AoS {x,y,theta,w} (32 B) <-> SoA.  One thread per particle; the AoS side moves
 // as two 16-byte accesses per lane.
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_tile_offsets(double* __r
 __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __restrict__ w, int n,
                                                              const double* __restrict__ tile_values,
                                                              int offsets_ready, double* __restrict__ cdf,
-                                                             int* __restrict__ zero_word)
+                                                             int* __restrict__ zero_word, int* __restrict__ guide)
 {
   __shared__ double s_wave[4];
   __shared__ double s_tile_off;
@@ -474,6 +476,25 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __re
       cdf[base + k + 1] = off + v[k];
   if (blockIdx.x == 0 && threadIdx.x == 0)
     cdf[0] = 0.0;
+  if (guide != nullptr)
+  {
+    // guide[j] = the i with c[i] <= j / kCdfGuide < c[i+1] (n where j / kCdfGuide >= c[n]).  This thread's view of
+    // c[base] can differ by an ulp from what its neighbour stored there, so an entry may stay unwritten or be
+    // off by one now and then: the reader verifies the bracket against the stored CDF and falls back (below).
+    double lo_c = (base == 0) ? 0.0 : off;
+#pragma unroll
+    for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+      if (base + k < (size_t)n)
+      {
+        const double hi_c = off + v[k];
+        for (int j = (int)ceil(lo_c * (double)kCdfGuide); j <= kCdfGuide && (double)j / (double)kCdfGuide < hi_c; ++j)
+          guide[j] = (int)(base + k);
+        if (base + k == (size_t)n - 1)
+          for (int j = (int)ceil(hi_c * (double)kCdfGuide); j <= kCdfGuide; ++j)
+            guide[j] = n;
+        lo_c = hi_c;
+      }
+  }
 }
 
 // Strict variant: the reference's serial chain, one lane.  Bit-exact, O(n) latency-bound;
@@ -521,6 +542,38 @@ __device__ __forceinline__ int cdf_find(const double* __restrict__ c, int n, dou
       hi = mid;
   }
   return lo;
+}
+
+// The same answer with a head start: guide[j] brackets the interval of every r in [j, j+1) / kCdfGuide, so the
+// bisection runs over a few elements instead of all n (17 dependent loads at n = 10^5 become ~8)
+__device__ __forceinline__ int cdf_find_guided(const double* __restrict__ c, int n, double r,
+                                               const int* __restrict__ guide)
+{
+  if (r >= 0.0 && r < 1.0)
+  {
+    const int j = (int)(r * (double)kCdfGuide);
+    int lo = guide[j];
+    if ((unsigned)lo < (unsigned)n)
+    {
+      const int g1 = guide[j + 1];
+      int hi = ((unsigned)g1 < (unsigned)n) ? g1 + 1 : n;
+      if (hi <= lo)
+        hi = n;
+      if (c[lo] <= r && r < c[hi])
+      {
+        while (hi - lo > 1)
+        {
+          const int mid = lo + ((hi - lo) >> 1);
+          if (c[mid] <= r)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        return lo;
+      }
+    }
+  }
+  return cdf_find(c, n, r);
 }
 
 // PFKDTree::insertPose key (pf_kdtree.cpp:52-54): floor(pose / {0.5, 0.5, 10 deg})
@@ -586,6 +639,7 @@ struct DrawArgs
   // a random free-space pose (nullptr: w_diff == 0, draw m tests element 2m+1 and takes r from 2m+2)
   const int* chain;
   FreeSpaceDev free_space;
+  const int* guide;  // CDF guide table from k_scan_final (nullable)
 };
 
 // Multinomial resampler body (particle_filter.cpp:381-414): with w_diff == 0 draw m consumes stream elements
@@ -663,7 +717,7 @@ __device__ __forceinline__ void draw_select_body(const DrawArgs& A)
   }
   else
   {
-    i = cdf_find(A.cdf, A.n_src, r);
+    i = (A.guide != nullptr) ? cdf_find_guided(A.cdf, A.n_src, r, A.guide) : cdf_find(A.cdf, A.n_src, r);
     if (i >= A.n_src)
     {
       atomicExch(A.miss_flag, 1);
