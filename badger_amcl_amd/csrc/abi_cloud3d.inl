@@ -293,11 +293,10 @@ int score_cloud(bpf_engine* e, ParticlesDev p, int n, const float* points_xyz, i
     uint64_t bits;
     std::memcpy(&bits, &rinv, 8);
     const bool exact_rinv = (bits & ((1ull << 24) - 1)) == 0 && std::fabs(std::fma(rinv, e->map3.resolution, -1.0)) < 1.1e-16;
-    ProfScope ps(e, BPF_K_SCORE);
     if (exact_rinv)
-      hipLaunchKernelGGL(k_cloud_score<true>, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
+      LAUNCH_TIMED(e, BPF_K_SCORE, k_cloud_score<true>, dim3(n_chunks, A.slabs), dim3(256), 0, A);
     else
-      hipLaunchKernelGGL(k_cloud_score<false>, dim3(n_chunks, A.slabs), dim3(256), 0, e->stream, A);
+      LAUNCH_TIMED(e, BPF_K_SCORE, k_cloud_score<false>, dim3(n_chunks, A.slabs), dim3(256), 0, A);
   }
   CloudFinishArgs F{};
   F.p = p;

@@ -1,6 +1,7 @@
 // libbadger_pf_hip.so -- host engine and C-ABI (include/badger_pf.h) for the MI355X
 // sensor-update + resample path.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <functional>

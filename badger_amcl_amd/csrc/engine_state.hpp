@@ -287,6 +287,7 @@ struct bpf_engine
 
   // ---- profiling
   bool profiling = false;
+  unsigned timed_launches = 0;  // scoring launches seen in profile mode 1 (every kTimedLaunchStride-th is timed)
   bool profile_all = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
   std::vector<int> ev_class;

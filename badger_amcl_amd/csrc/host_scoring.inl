@@ -295,13 +295,12 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
       e->last_used_window_path = true;
     }
   }
-  ProfScope ps(e, BPF_K_SCORE);
   if (count_only)
-    hipLaunchKernelGGL((k_score_field<true, false>), dim3(grid), dim3(256), lds, e->stream, A);
+    LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<true, false>), dim3(grid), dim3(256), lds, A);
   else if (table_lds)
-    hipLaunchKernelGGL((k_score_field<false, true>), dim3(grid), dim3(256), lds, e->stream, A);
+    LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true>), dim3(grid), dim3(256), lds, A);
   else
-    hipLaunchKernelGGL((k_score_field<false, false>), dim3(grid), dim3(256), lds, e->stream, A);
+    LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, false>), dim3(grid), dim3(256), lds, A);
   HIPCHK(e, hipGetLastError());
   return BPF_OK;
 }
@@ -493,10 +492,7 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
       A.block_partials = e->d_block_partials.p;
       e->fused_partials = grid;
     }
-    {
-      ProfScope ps(e, BPF_K_SCORE);
-      hipLaunchKernelGGL(k_score_beam, dim3(grid), dim3(256), bytes, e->stream, A);
-    }
+    LAUNCH_TIMED(e, BPF_K_SCORE, k_score_beam, dim3(grid), dim3(256), bytes, A);
     HIPCHK(e, hipGetLastError());
     e->evals_last = (long long)n * (long long)beams.size();
     return release_slot(e, s);

@@ -446,9 +446,11 @@ typedef struct
   double ms[BPF_K_COUNT];          /* accumulated HIP-event time per kernel class */
   long long launches[BPF_K_COUNT];
 } bpf_profile;
-/* on = 1: every launch of the dominant (scoring) kernel is bracketed by hipEvents on the engine
- * stream (two event records per update); on = 2: every kernel class is (costs ~2 us of host time
- * per event, so not for timed regions); 0: off. */
+/* on = 1: every 4th launch of the dominant (scoring) kernel is timed by a pair of hipEvents attached to the
+ * dispatch itself (hipExtLaunchKernelGGL: the kernel's own start-to-end on the engine stream, which is what the
+ * rocprofv3 kernel trace reports; a timed dispatch costs the update ~5 us, hence the sampling -- `launches` counts
+ * the timed ones); on = 2: every scoring launch that way and every other kernel class bracketed by hipEventRecord
+ * (costs host time per event, so not for timed regions); 0: off. */
 int bpf_profile_enable(bpf_engine* e, int on);
 int bpf_profile_reset(bpf_engine* e);
 int bpf_profile_get(bpf_engine* e, bpf_profile* out);
