@@ -287,6 +287,27 @@ int score_cloud(bpf_engine* e, ParticlesDev p, int n, const float* points_xyz, i
   A.table = e->d_cloud_table.p;
   A.partials = e->d_cloud_partials.p;
   A.slabs = std::max(1, std::min(blocks_for(n, 4), std::max(1, (e->n_cu * 6) / n_chunks)));
+  for (int k = 0; k < 8; ++k)
+    A.round_count[k] = A.round_base[k] = A.round_first_slab[k] = 0;
+  A.n_rounds = 0;
+  if (e->graded_shares && n_chunks * A.slabs == e->n_cu * 6 && e->n_cu % n_chunks == 0 && n >= A.slabs * 4 * 64)
+  {
+    // graded partition as in the planar kernel: blocks are placed in linear order (x fastest), n_cu per round, and the
+    // SIMD favours its oldest wave; with equal shares the six rounds end at 12.3 / 13.5 / 14.9 / 16.6 / 18.3 / 20.2 ms
+    // (tools/cloud_span.py).  Shares ~ end^-1.5, the exponent that fits the planar kernel's measured optimum.
+    static const double kShare[6] = { 0.246, 0.219, 0.185, 0.148, 0.114, 0.088 };
+    const int slabs_per_round = e->n_cu / n_chunks;
+    const double per_slot = (double)n / (slabs_per_round * 4);  // particles of one (slab, wave) slot over all rounds
+    int base = 0;
+    for (int r = 0; r < 6; ++r)
+    {
+      A.round_count[r] = std::max(1, (int)std::ceil(per_slot * kShare[r]));
+      A.round_base[r] = base;
+      A.round_first_slab[r] = r * slabs_per_round;
+      base += A.round_count[r] * slabs_per_round * 4;
+    }
+    A.n_rounds = 6;
+  }
   {
     // exact reciprocal?  1/res must fit 29 bits (so float * rinv is exact) and rinv*res must round to 1
     const double rinv = e->map3.inv_resolution;

@@ -100,6 +100,14 @@ const char* bpf_score_kernel_name(const bpf_engine* e)
 }
 
 #ifdef BPF_PHASE_TIMING
+int bpf_debug_cloud_span(unsigned long long* out, int n_waves)
+{
+  if (n_waves > 8192)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cloud_span), (size_t)n_waves * 2 * sizeof(unsigned long long)) != hipSuccess)
+    return BPF_ERR_HIP;
+  return BPF_OK;
+}
 // diagnostic builds only (not in badger_pf.h): rows of the last k_score_field launch, see tools/phase_timing.py
 int bpf_debug_phase_cycles(unsigned long long* out, int n_waves)
 {

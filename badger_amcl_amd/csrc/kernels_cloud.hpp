@@ -120,12 +120,26 @@ struct CloudScoreArgs
   const double* table;   // [257]: per distance ratio, [256] = off map
   double* partials;      // [n_chunks][n]
   int slabs;
+  // graded partition (round_count[0] > 0, see k_score_field): the waves of slab y own round_count[r] particles each,
+  // r = the placement round of the slab's blocks, starting at round_base[r] + ((y - round_first_slab[r]) * 4 + wave)
+  // * round_count[r]
+  int round_count[8];
+  int round_base[8];
+  int round_first_slab[8];
+  int n_rounds;
 };
+
+#ifdef BPF_PHASE_TIMING
+__device__ unsigned long long g_cloud_span[8192][2];  // diagnostic builds: per-wave start / end (100 MHz clock)
+#endif
 
 template <bool EXACT_RINV>
 __global__ __launch_bounds__(256) void k_cloud_score(const CloudScoreArgs A)
 {
 #pragma clang fp contract(off)
+#ifdef BPF_PHASE_TIMING
+  const long long _w0 = wall_clock64();
+#endif
   __shared__ float s_pts[3][kCloudChunk];
   __shared__ double s_table[257];
   const int chunk = blockIdx.x;
@@ -145,7 +159,17 @@ __global__ __launch_bounds__(256) void k_cloud_score(const CloudScoreArgs A)
   const Map3dDev& M = A.map;
   const int span_x = M.max_c[0] - M.min_c[0], span_y = M.max_c[1] - M.min_c[1], span_z = M.max_c[2] - M.min_c[2];
 
-  for (int jv = blockIdx.y * 4 + wave; jv < A.n; jv += A.slabs * 4)
+  int j_begin = blockIdx.y * 4 + wave, j_end = A.n, j_step = A.slabs * 4;
+  if (A.round_count[0] > 0)
+  {
+    int r = 0;
+    while (r + 1 < A.n_rounds && (int)blockIdx.y >= A.round_first_slab[r + 1])
+      ++r;
+    j_begin = min(A.n, A.round_base[r] + (((int)blockIdx.y - A.round_first_slab[r]) * 4 + wave) * A.round_count[r]);
+    j_end = min(A.n, j_begin + A.round_count[r]);
+    j_step = 1;
+  }
+  for (int jv = j_begin; jv < j_end; jv += j_step)
   {
     // the particle index is wave-uniform: make it scalar so the affine comes in through s_load
     const int j = __builtin_amdgcn_readfirstlane(jv);
@@ -200,6 +224,17 @@ __global__ __launch_bounds__(256) void k_cloud_score(const CloudScoreArgs A)
     if (lane == 0)
       A.partials[(size_t)chunk * A.n + j] = tot;
   }
+#ifdef BPF_PHASE_TIMING
+  if (lane == 0)
+  {
+    const int _w = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+    if (_w < 8192)
+    {
+      g_cloud_span[_w][0] = (unsigned long long)_w0;
+      g_cloud_span[_w][1] = (unsigned long long)wall_clock64();
+    }
+  }
+#endif
 }
 
 struct CloudFinishArgs
