@@ -107,6 +107,14 @@ def setup_engine(args, wl, device):
     return e, m, sc, pf, data, lut
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "particle-beam evals/sec (sensor update+resample), 100k particles\u00d71081 beams"
+
+
 def cpu_baseline(args, wl, lut, budget_s):
     """The oracle (a port of the reference's CPU path) timed on this box's host cores: 1 thread,
     same workload, as many whole steps as fit the budget (at least one)."""
@@ -361,7 +369,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "particle-beam evals/sec (sensor update+resample), 100k particles x 1081 beams",
+            "metric": baseline_metric(),
             "value": value, "unit": "particle-beam evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
