@@ -203,3 +203,69 @@ def test_engines_release_their_memory(orc):
         cycle()
     free1 = free_bytes()
     assert free0 - free1 < 32 << 20, (free0, free1)
+
+
+def test_graded_and_equal_shares_give_the_same_weights(engine, world):
+    """BPF_OPT_GRADED_SHARES only changes which wave scores which particle: per-particle weights are bit-identical,
+    the total differs at most by its summation order (100 k x 1081, the size where the graded partition is on)."""
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    n = 100000
+    s = synth.converged_cloud(n, world["pose"], seed=21)
+    s[:, 3] = np.random.default_rng(5).uniform(0.5, 1.5, n) / n
+    out = {}
+    for mode in (1, 0):
+        engine.set_option(hpf.OPT_GRADED_SHARES, mode)
+        try:
+            got = s.copy()
+            total = world["sc"].applyModelToSampleSet(world["data"], got, 0)
+            out[mode] = (got[:, 3].copy(), total)
+        finally:
+            engine.set_option(hpf.OPT_GRADED_SHARES, 1)
+    assert np.array_equal(out[1][0], out[0][0])
+    assert abs(out[1][1] - out[0][1]) <= 1e-12 * out[0][1]
+
+
+def test_graded_shares_3d(engine, orc):
+    """The same for the 3-D kernel at a size where its graded partition is on (12 288 particles x 65 536 points),
+    plus an oracle spot check on a slice of the particles."""
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    pi, dr, mn, mx = synth.box_room_lut()
+    pts = synth.grid_cloud(64, 1024)
+    n = 12288
+    rng = np.random.default_rng(8)
+    s = np.zeros((n, 4))
+    s[:, 0] = 0.3 + rng.normal(0, 0.1, n)
+    s[:, 1] = 0.2 + rng.normal(0, 0.1, n)
+    s[:, 2] = rng.normal(0, 0.05, n)
+    s[:, 3] = rng.uniform(0.5, 1.5, n) / n
+    om = bpf.OctoMap(engine, 0.05)
+    om.setDistancesLUT(pi, dr, mn, mx, 0.3)
+    sc = bpf.PointCloudScanner(engine)
+    sc.init(65536, om)
+    sc.setPointCloudModel(0.5, 0.05, 0.1)
+    sc.setMapFactors(0.95, 0.95, 0.3)
+    tf_xyz, tf_quat = (0.0, 0.0, 0.6), (0.0, 0.0, 0.0, 1.0)
+    sc.setPointCloudScannerToFootprintTF(tf_xyz, tf_quat)
+    data = bpf.PointCloudData(pts)
+    out = {}
+    for mode in (1, 0):
+        engine.set_option(hpf.OPT_GRADED_SHARES, mode)
+        try:
+            got = s.copy()
+            total = sc.applyModelToSampleSet(data, got)
+            out[mode] = (got[:, 3].copy(), total)
+        finally:
+            engine.set_option(hpf.OPT_GRADED_SHARES, 1)
+    assert np.array_equal(out[1][0], out[0][0])
+    assert abs(out[1][1] - out[0][1]) <= 1e-12 * out[0][1]
+    # oracle on 24 of the particles (65 536 points each)
+    idx = np.linspace(0, n - 1, 24).astype(int)
+    olut = orc.OctoMapLUT(mn, mx, 0.05, 0.3, pi, dr)
+    op = orc.cloud(orc.CLOUD_MODEL, 65536, tf_xyz, tf_quat, z_hit=0.5, z_rand=0.05, sigma_hit=0.1)
+    op.off_map_factor = 0.95
+    want = np.ascontiguousarray(s[idx])
+    orc.cloud_apply(op, olut, want, pts)
+    rel = np.abs(out[1][0][idx] - want[:, 3]) / want[:, 3]
+    assert (rel > 1e-9).sum() <= 1  # one point within rounding of a voxel face may resolve differently
