@@ -40,6 +40,7 @@ void bpf_destroy(bpf_engine* e)
     if (s.done)
       (void)hipEventDestroy(s.done);
   }
+  mailbox_release(e);
   if (e->targets_read)
     (void)hipEventDestroy(e->targets_read);
   for (auto ev : e->ev_start)
@@ -65,6 +66,7 @@ const char* bpf_error_string(int code)
     case BPF_ERR_LUT_LEVELS: return "distance LUT has too many distinct values";
     case BPF_ERR_BEAM_STEP: return "beam model step is zero (reference never returns)";
     case BPF_ERR_CAPACITY: return "capacity exceeded";
+    case BPF_ERR_EXCHANGE: return "exchange between the shards failed (a peer did not answer in time)";
     default: return "unknown";
   }
 }

@@ -2,6 +2,19 @@
 // ---------------------------------------------------------------------- sharded stages
 namespace
 {
+// two-launch sum of the weights into scalars[0]; with a mailbox a third, tiny launch posts it to the peers
+int shard_sum_and_post(bpf_engine* e, const double* w, int n)
+{
+  int rc = sum_into_slot(e, w, n, 0, 0, n);
+  if (rc != BPF_OK || !e->mb.active)
+    return rc;
+  const unsigned long long gen = ++e->mb.tot_gen;
+  hipLaunchKernelGGL(k_mailbox_post_total, dim3(1), dim3(64), 0, e->stream, &e->d_scalars.p->v[0], mailbox_dev(e),
+                     (int)(gen & 1), gen);
+  HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
 // local weight total into scalars[0] after a sharded scoring stage
 int shard_local_total(bpf_engine* e)
 {
@@ -10,13 +23,15 @@ int shard_local_total(bpf_engine* e)
   {
     // the scoring kernel left per-block partials: one small launch folds them into the local total
     ProfScope ps(e, BPF_K_REDUCE);
+    // with a mailbox the same launch stores the total into every peer's memory
+    const unsigned long long gen = e->mb.active ? ++e->mb.tot_gen : 0;
     hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
-                       e->fused_partials, e->d_scalars.p, 0);
+                       e->fused_partials, e->d_scalars.p, 0, mailbox_dev(e), (int)(gen & 1), gen);
     HIPCHK(e, hipGetLastError());
     e->fused_partials = 0;
     return BPF_OK;
   }
-  return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
+  return shard_sum_and_post(e, s.w.p, e->sample_count);
 }
 }  // namespace
 
@@ -84,7 +99,7 @@ int bpf_shard_score_cloud(bpf_engine* e, const float* points_xyz, int n_points)
   int rc = score_cloud(e, s.dev(), e->sample_count, points_xyz, n_points);
   if (rc != BPF_OK)
     return rc;
-  return sum_into_slot(e, s.w.p, e->sample_count, 0, 0, e->sample_count);
+  return shard_sum_and_post(e, s.w.p, e->sample_count);
 }
 
 int bpf_shard_scalars_dev(bpf_engine* e, void** dev_ptr)
@@ -108,10 +123,19 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
   const int n = e->sample_count;
   const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
   HIPCHK(e, e->d_tile_sums.reserve((size_t)nb));
+  // totals that are this engine's mailbox slots: the kernel itself waits for the peers' posts of this update
+  MailboxDev wait{};
+  if (mailbox_owns(e, totals_dev))
+  {
+    if (world != e->mb.world)
+      return e->fail(BPF_ERR_INVALID_ARGUMENT, "mailbox totals: world differs from the mailbox's");
+    wait = mailbox_dev(e);
+  }
   ProfScope ps(e, BPF_K_NORMALIZE);
   hipLaunchKernelGGL(k_normalize_gathered, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
                      static_cast<const double*>(totals_dev), world, global_sample_count, e->d_scalars.p,
-                     e->alpha_slow, e->alpha_fast, e->d_tile_sums.p);
+                     e->alpha_slow, e->alpha_fast, e->d_tile_sums.p, wait, (int)(e->mb.tot_gen & 1),
+                     e->mb.tot_gen);
   HIPCHK(e, hipGetLastError());
   e->tile_sums_n = n;
   return BPF_OK;
@@ -122,15 +146,43 @@ int bpf_shard_build_cdf(bpf_engine* e, void* flags_dev)
   if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
-  if (flags_dev)
-    HIPCHK(e, hipMemsetAsync(flags_dev, 0, sizeof(int), e->stream));
-  int rc = build_cdf(e, e->sets[e->cur].w.p, e->sample_count);
-  if (rc != BPF_OK)
-    return rc;
-  HIPCHK(e, hipMemcpyAsync(&e->d_scalars.p->v[7], e->d_cdf.p + e->sample_count, sizeof(double),
-                           hipMemcpyDeviceToDevice, e->stream));
+  // the scan clears the caller's miss flag and leaves the local CDF sum in scalars[7] itself
+  return build_cdf(e, e->sets[e->cur].w.p, e->sample_count, static_cast<int*>(flags_dev), &e->d_scalars.p->v[7]);
+}
+
+namespace
+{
+// A window handed out by bpf_shard_mailbox_window: the draw kernel stores every column it owns into all peers'
+// copies of that window and posts "done"; the window's first consumer kernel waits for every shard's word.
+int shard_window_exchange(bpf_engine* e, const void* window_dev, int count, int world, WindowArgs* A)
+{
+  if (!mailbox_owns(e, window_dev))
+    return BPF_OK;
+  const unsigned long long g = e->mb.win_gen;
+  const char* expect = e->mb.own + kMailboxHeader + (size_t)(g & 1) * 6 * (size_t)e->mb.max_window * sizeof(long long);
+  if (window_dev != expect || e->mb.win_wait)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "mailbox window: take a fresh one from bpf_shard_mailbox_window per exchange");
+  if (count > e->mb.max_window || world != e->mb.world)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "mailbox window: count beyond max_window, or another world size");
+  A->mb = mailbox_dev(e);
+  A->mb_parity = (int)(g & 1);
+  A->mb_gen = g;
+  A->mb_counter = e->d_mb_counter.p;
+  e->mb.win_wait = true;
   return BPF_OK;
 }
+
+// wait arguments for the first kernel that reads an exchanged window (gen 0 / world 0: nothing to wait for)
+MailboxDev shard_window_wait(bpf_engine* e, const void* window_dev)
+{
+  if (mailbox_owns(e, window_dev) && e->mb.win_wait)
+  {
+    e->mb.win_wait = false;
+    return mailbox_dev(e);
+  }
+  return MailboxDev{};
+}
+}  // namespace
 
 int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev,
                               int sums_are_totals, int rank, int world, void* window_dev, int stride, void* flags_dev)
@@ -154,6 +206,9 @@ int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m
   A.window = static_cast<long long*>(window_dev);
   A.stride = stride;
   A.flags = static_cast<int*>(flags_dev);
+  int rcm = shard_window_exchange(e, window_dev, m1 - m0, world, &A);
+  if (rcm != BPF_OK)
+    return rcm;
   if (e->shard_chain)
   {
     // w_diff > 0 (bpf_shard_begin_resample built the chain from this same stream state)
@@ -309,13 +364,16 @@ int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_ke
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, e->h_keys.reserve((size_t)n_keys * 3));
   const unsigned generation = ++e->done_generation;
+  const MailboxDev wait = shard_window_wait(e, window_dev);
   hipLaunchKernelGGL(k_publish_window_keys, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
                      static_cast<const long long*>(window_dev), stride, n_keys, e->h_keys.p,
                      reinterpret_cast<unsigned*>(e->d_flags.p + 4), reinterpret_cast<volatile unsigned*>(e->h_done.p),
-                     generation);
+                     generation, wait, (int)(e->mb.win_gen & 1), e->mb.win_gen);
   HIPCHK(e, hipGetLastError());
   if (!wait_generation(e, generation))
     HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (int rcx = mailbox_check(e))
+    return rcx;
   return bpf_kld_feed(e, e->h_keys.p, 0, n_keys, n_keys, first_draw_index, stop_count_out);
 }
 
@@ -463,6 +521,9 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
   A.stride = stride;
   A.flags = static_cast<int*>(flags_dev);
   A.targets = e->h_targets.p;
+  int rcm = shard_window_exchange(e, window_dev, count, world, &A);
+  if (rcm != BPF_OK)
+    return rcm;
   {
     ProfScope ps(e, BPF_K_DRAW);
     hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream, A);
@@ -500,13 +561,16 @@ int bpf_kld_insert_dev(bpf_engine* e, const void* window_dev, int stride, int n_
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, e->h_keys.reserve((size_t)n_keys * 3));
   const unsigned generation = ++e->done_generation;
+  const MailboxDev wait = shard_window_wait(e, window_dev);
   hipLaunchKernelGGL(k_publish_window_keys, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
                      static_cast<const long long*>(window_dev), stride, n_keys, e->h_keys.p,
                      reinterpret_cast<unsigned*>(e->d_flags.p + 4), reinterpret_cast<volatile unsigned*>(e->h_done.p),
-                     generation);
+                     generation, wait, (int)(e->mb.win_gen & 1), e->mb.win_gen);
   HIPCHK(e, hipGetLastError());
   if (!wait_generation(e, generation))
     HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (int rcx = mailbox_check(e))
+    return rcx;
   return bpf_kld_insert(e, e->h_keys.p, 0, n_keys, n_keys);
 }
 
@@ -520,14 +584,18 @@ int bpf_kld_stop_dev(bpf_engine* e, const void* window_dev, int stride, int n_ke
     return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, e->d_keys.reserve((size_t)n_keys * 3));
+  const MailboxDev wait = shard_window_wait(e, window_dev);
   hipLaunchKernelGGL(k_window_keys_to_aos, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
-                     static_cast<const long long*>(window_dev), stride, n_keys, e->d_keys.p);
+                     static_cast<const long long*>(window_dev), stride, n_keys, e->d_keys.p, wait,
+                     (int)(e->mb.win_gen & 1), e->mb.win_gen);
   HIPCHK(e, hipGetLastError());
   bool handled = false;
   *stop_count_out = -1;
   *leaf_count_out = *bin_count_out = 0;
   int rc = kld_tree_on_device(e, n_keys, &handled, stop_count_out, leaf_count_out, bin_count_out);
   *handled_out = handled ? 1 : 0;
+  if (rc == BPF_OK)
+    rc = mailbox_check(e);
   return rc;
 }
 

@@ -39,6 +39,10 @@ namespace
 
 // ====================================================================== C-ABI (include/badger_pf.h)
 extern "C" {
+namespace
+{
+void mailbox_release(bpf_engine* e);  // abi_mailbox.inl
+}
 #include "abi_lifecycle.inl"
 #include "abi_map2d.inl"
 #include "abi_planar.inl"
@@ -48,6 +52,7 @@ extern "C" {
 #include "abi_lut_reference.inl"
 #include "abi_wire.inl"
 #include "abi_cloud3d.inl"
+#include "abi_mailbox.inl"
 #include "abi_sharded.inl"
 #include "abi_measure.inl"
 }  // extern "C"

@@ -258,6 +258,25 @@ struct bpf_engine
   DevBuf<int> d_chain_cnt, d_chain_exit, d_chain_entry, d_chain_base, d_chain;
   PinnedBuf<int> h_chain_word;
 
+  // ---- mailbox exchange of the sharded path (kernels_mailbox.hpp, abi_mailbox.inl)
+  struct Mailbox
+  {
+    bool active = false;            // created AND connected
+    int rank = 0, world = 0;
+    long long max_window = 0;
+    size_t bytes = 0;
+    char* own = nullptr;            // this engine's mailbox (uncached device memory, exported by IPC handle)
+    char* peer[kMailboxMaxWorld] = {};
+    bool opened[kMailboxMaxWorld] = {};
+    unsigned long long tot_gen = 0; // generation of the last totals post
+    unsigned long long win_gen = 0; // generation of the window handed out last
+    bool win_wait = false;          // that window's columns are in flight: its first consumer kernel has to wait
+    unsigned long long hello = 0;
+  } mb;
+  PinnedBuf<unsigned> h_mb_error;
+  PinnedBuf<int> h_mb_result;
+  DevBuf<unsigned> d_mb_counter;
+
   // ---- KLD stop rule on the device (long draw streams)
   int kld_device_min = 8192;  // draws left after the first window from which the device tree takes over
   bool kld_device_used = false;

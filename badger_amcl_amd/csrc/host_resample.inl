@@ -16,7 +16,9 @@ int fetch_scalars(bpf_engine* e)
   return BPF_OK;
 }
 
-int build_cdf(bpf_engine* e, const double* w, int n)
+// zero_word2 / sum_out (optional): a second miss flag to clear and where to leave c[n], both written by the scan
+// itself instead of by a memset and a copy behind it
+int build_cdf(bpf_engine* e, const double* w, int n, int* zero_word2 = nullptr, double* sum_out = nullptr)
 {
   HIPCHK(e, e->d_cdf.reserve((size_t)n + 1));
   if (!e->d_cdf_guide.p)
@@ -30,6 +32,10 @@ int build_cdf(bpf_engine* e, const double* w, int n)
   {
     hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, e->stream, w, n, e->d_cdf.p);
     HIPCHK(e, hipMemsetAsync(e->d_flags.p, 0, sizeof(int), e->stream));
+    if (zero_word2)
+      HIPCHK(e, hipMemsetAsync(zero_word2, 0, sizeof(int), e->stream));
+    if (sum_out)
+      HIPCHK(e, hipMemcpyAsync(sum_out, e->d_cdf.p + n, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   }
   else
   {
@@ -50,13 +56,13 @@ int build_cdf(bpf_engine* e, const double* w, int n)
     {
       // few tiles: every block of the final pass forms its own offset (one launch less)
       hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 0, e->d_cdf.p,
-                         e->d_flags.p, e->d_cdf_guide.p);
+                         e->d_flags.p, e->d_cdf_guide.p, zero_word2, sum_out);
     }
     else
     {
       hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, tiles, nb, e->d_flags.p);
       hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, w, n, tiles, 1, e->d_cdf.p,
-                         nullptr, e->d_cdf_guide.p);
+                         nullptr, e->d_cdf_guide.p, zero_word2, sum_out);
     }
   }
   HIPCHK(e, hipGetLastError());

@@ -1,0 +1,140 @@
+// Exchange between the engines of one node without a collective library ("mailbox").
+//
+// The sharded path has two exchanges per update, both tiny: W weight totals (8 B each) and one draw window
+// in which every column has exactly one writer.  Neither is a reduction, so every rank can simply store its
+// contribution into every peer's memory over xGMI: each engine owns one uncached device allocation, exports
+// it through an IPC handle, and maps the W - 1 others.  A producer kernel writes its values into the same
+// slot of every peer's mailbox and then a generation word with system-scope release; a consumer kernel spins
+// (bounded) on the generation words in its OWN mailbox with system-scope acquire.  No host round trip, no
+// extra launch: the post rides on the kernel that produces the value (k_fold_partials, k_draw_window) and
+// the wait on the kernel that consumes it (k_normalize_gathered, k_publish_window_keys).
+//
+// Two parities per slot: generation g uses parity g & 1.  A rank can start exchange g + 2 only after it has
+// seen every peer's word of g + 1, which that peer posts (in stream order) after it consumed g, so a slot
+// is never overwritten while somebody still reads it.
+//
+// Layout of one mailbox (bytes):   0  tot_gen [2][16] u64     totals: generation words
+//                                256  tot_val [2][16] f64     totals: values
+//                                512  win_done[2][16] u64     window: "rank r has written all its columns"
+//                                768  hello   [16]    u64     connect-time self-test
+//                               4096  win     [2][6][max_window] i64
+#pragma once
+#include "device_types.hpp"
+
+namespace bpf
+{
+
+constexpr int kMailboxMaxWorld = 16;
+constexpr size_t kMailboxHeader = 4096;
+constexpr long long kMailboxTimeoutTicks = 500000000ll;  // 5 s of the 100 MHz wall clock
+
+struct MailboxDev
+{
+  int rank, world;                // world == 0: no mailbox (the kernels skip their post / wait)
+  long long max_window;           // columns per window row
+  char* peer[kMailboxMaxWorld];   // every rank's mailbox as mapped into this process (own included)
+  unsigned* host_error;           // pinned host word: set to 1 by a wait that ran out of time
+};
+
+__device__ __forceinline__ unsigned long long* mb_tot_gen(char* base, int parity, int r)
+{
+  return reinterpret_cast<unsigned long long*>(base) + parity * kMailboxMaxWorld + r;
+}
+__device__ __forceinline__ double* mb_tot_val(char* base, int parity, int r)
+{
+  return reinterpret_cast<double*>(base + 256) + parity * kMailboxMaxWorld + r;
+}
+__device__ __forceinline__ unsigned long long* mb_win_done(char* base, int parity, int r)
+{
+  return reinterpret_cast<unsigned long long*>(base + 512) + parity * kMailboxMaxWorld + r;
+}
+__device__ __forceinline__ unsigned long long* mb_hello(char* base, int r)
+{
+  return reinterpret_cast<unsigned long long*>(base + 768) + r;
+}
+__device__ __forceinline__ long long* mb_window(char* base, int parity, long long max_window)
+{
+  return reinterpret_cast<long long*>(base + kMailboxHeader) + (size_t)parity * 6 * (size_t)max_window;
+}
+
+// bounded spin until *slot >= gen; false when the 5 s ran out (every wave reaches the exit either way)
+__device__ __forceinline__ bool mb_spin_ge(const unsigned long long* slot, unsigned long long gen)
+{
+  const long long t0 = wall_clock64();
+  for (;;)
+  {
+    if (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= gen)
+      return true;
+    if (wall_clock64() - t0 > kMailboxTimeoutTicks)
+      return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// Block-wide wait on `world` generation words of this rank's own mailbox (threads 0 .. world-1 spin, the
+// rest wait at the barrier); every thread of the block must call it.
+__device__ __forceinline__ void mb_block_wait(const MailboxDev& M, unsigned long long* first_slot,
+                                              unsigned long long gen)
+{
+  if ((int)threadIdx.x < M.world)
+    if (!mb_spin_ge(first_slot + threadIdx.x, gen))
+      __hip_atomic_store(M.host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // what the peers wrote before their words is visible to every thread
+}
+
+// thread t < world stores this rank's total into peer t's mailbox, then the generation word
+__device__ __forceinline__ void mb_post_total(const MailboxDev& M, int parity, unsigned long long gen, double value)
+{
+  if ((int)threadIdx.x < M.world)
+  {
+    char* base = M.peer[threadIdx.x];
+    *mb_tot_val(base, parity, M.rank) = value;
+    __hip_atomic_store(mb_tot_gen(base, parity, M.rank), gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// After a grid has stored its window columns into the peers: the last block to get here posts "done".
+// Every thread of every block must call it.
+__device__ __forceinline__ void mb_window_done_when_last(const MailboxDev& M, int parity, unsigned long long gen,
+                                                         unsigned* counter)
+{
+  __threadfence_system();  // this thread's peer stores have landed
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const unsigned prev = atomicAdd(counter, 1u);
+    if (prev == gridDim.x - 1)
+    {
+      *counter = 0;
+      for (int r = 0; r < M.world; ++r)
+        __hip_atomic_store(mb_win_done(M.peer[r], parity, M.rank), gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// the local total of a scoring stage that did not go through k_fold_partials (3-D path, beam model)
+__global__ void k_mailbox_post_total(const double* value, const MailboxDev M, int parity, unsigned long long gen)
+{
+  mb_post_total(M, parity, gen, *value);
+}
+
+// connect-time self-test: one full round (post to every peer, wait for every peer); result[0] = 1 when all arrived
+__global__ void k_mailbox_hello(const MailboxDev M, unsigned long long token, int* result)
+{
+  __shared__ int s_ok;
+  if (threadIdx.x == 0)
+    s_ok = 1;
+  __syncthreads();
+  if ((int)threadIdx.x < M.world)
+  {
+    __hip_atomic_store(mb_hello(M.peer[threadIdx.x], M.rank), token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!mb_spin_ge(mb_hello(M.peer[M.rank], threadIdx.x), token))
+      atomicExch(&s_ok, 0);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    result[0] = s_ok;
+}
+
+}  // namespace bpf

@@ -3,6 +3,7 @@
 // distance-LUT construction.
 #pragma once
 #include "device_types.hpp"
+#include "kernels_mailbox.hpp"
 #include "kernels_score.hpp"
 
 namespace bpf
@@ -253,8 +254,10 @@ __global__ __launch_bounds__(1024) void k_resample_tail_small(const double* __re
 }
 
 // folds the scoring kernel's per-block weight partials into scalars[slot] (sharded path: the local total)
+// With a mailbox (kernels_mailbox.hpp) the total also goes straight into every peer's memory.
 __global__ __launch_bounds__(BPF_RED_BLOCK) void k_fold_partials(const double* __restrict__ partials, int n_partials,
-                                                                FilterScalars* sc, int slot)
+                                                                FilterScalars* sc, int slot, const MailboxDev M,
+                                                                int post_parity, unsigned long long post_gen)
 {
   __shared__ double s_wave[4];
   double acc = 0.0;
@@ -263,6 +266,8 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_fold_partials(const double* _
   const double tot = block_sum_256(acc, s_wave);
   if (threadIdx.x == 0)
     sc->v[slot] = tot;
+  if (M.world > 0)
+    mb_post_total(M, post_parity, post_gen, tot);
 }
 
 // Sharded tail for a small resampled set (one block): this rank adopts poses [lo, hi) of the assembled
@@ -332,12 +337,16 @@ __global__ __launch_bounds__(1024) void k_shard_tail_small(const double* __restr
 // thread 0 of block 0 also applies the running-average update with the global numbers.  Tiles of
 // 2048 weights per block; each block leaves its tile's sum of normalised weights for the CDF.
 __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered(double* __restrict__ w, int n,
-                                                                     const double* __restrict__ totals, int world,
+                                                                     const double* totals, int world,
                                                                      int global_n, FilterScalars* sc,
                                                                      double alpha_slow, double alpha_fast,
-                                                                     double* __restrict__ tile_sums)
+                                                                     double* __restrict__ tile_sums,
+                                                                     const MailboxDev M, int wait_parity,
+                                                                     unsigned long long wait_gen)
 {
   __shared__ double s_wave[4];
+  if (M.world > 0)  // `totals` are this rank's mailbox slots: wait until every peer's total of this update is in
+    mb_block_wait(M, mb_tot_gen(M.peer[M.rank], wait_parity, 0), wait_gen);
   double total = 0.0;
   for (int r = 0; r < world; ++r)
     total += totals[r];
@@ -435,7 +444,9 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_tile_offsets(double* __r
 __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __restrict__ w, int n,
                                                              const double* __restrict__ tile_values,
                                                              int offsets_ready, double* __restrict__ cdf,
-                                                             int* __restrict__ zero_word, int* __restrict__ guide)
+                                                             int* __restrict__ zero_word, int* __restrict__ guide,
+                                                             int* __restrict__ zero_word2 = nullptr,
+                                                             double* __restrict__ sum_out = nullptr)
 {
   __shared__ double s_wave[4];
   __shared__ double s_tile_off;
@@ -450,6 +461,8 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __re
     s_tile_off = off;
     if (blockIdx.x == 0 && zero_word != nullptr)
       *zero_word = 0;  // the CDF-miss flag of the draw kernels that follow
+    if (blockIdx.x == 0 && zero_word2 != nullptr)
+      *zero_word2 = 0;  // the caller's copy of that flag (sharded stages)
   }
   const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
   double v[BPF_RED_PER_THREAD];
@@ -473,7 +486,11 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_scan_final(const double* __re
 #pragma unroll
   for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
     if (base + k < (size_t)n)
+    {
       cdf[base + k + 1] = off + v[k];
+      if (sum_out != nullptr && base + k == (size_t)n - 1)
+        *sum_out = off + v[k];  // c[n]: the local CDF sum a shard publishes
+    }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     cdf[0] = 0.0;
   if (guide != nullptr)
@@ -796,14 +813,18 @@ struct WindowArgs
   int n_random;
   int write_random;
   FreeSpaceDev free_space;
+  // mailbox exchange (mb.world > 0): a column is stored by its one owner into every peer's window instead of
+  // being summed over the shards afterwards; `window` is not used
+  MailboxDev mb;
+  int mb_parity;
+  unsigned long long mb_gen;
+  unsigned* mb_counter;
 };
 
-__global__ void k_draw_window(const WindowArgs A)
+// one draw of the window: true when this shard owns column o (out[] then holds pose bits + key)
+__device__ __forceinline__ bool draw_window_column(const WindowArgs& A, int o, long long out[6])
 {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
   const int m = A.m0 + o;
-  if (m >= A.m1)
-    return;
   // Slice of the global CDF owned by this shard.  With CDF sums the slices tile [0, total) exactly.
   // With weight totals (one exchange less) the slice of shard q is defined as total_q / T, the same
   // quotient on every rank; the shard's own running sum is used inside it and its last particle
@@ -850,9 +871,11 @@ __global__ void k_draw_window(const WindowArgs A)
     const uint64_t xs = lcg_skip(A.rng_state, 2ull * (uint64_t)m + 2ull, A.jump);
     r = ldexp((double)xs, -48);
   }
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    out[k] = 0;
   if (random)
   {
-    long long out[6] = { 0, 0, 0, 0, 0, 0 };
     if (A.write_random)
     {
       int key[3];
@@ -864,14 +887,10 @@ __global__ void k_draw_window(const WindowArgs A)
       out[4] = key[1];
       out[5] = key[2];
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-      A.window[(size_t)k * A.stride + o] = out[k];
-    return;
+    return A.write_random != 0;
   }
   const bool last = A.rank == A.world - 1;
   const bool mine = (r >= offset) && (r < top || last);
-  long long out[6] = { 0, 0, 0, 0, 0, 0 };
   if (mine)
   {
     int i;
@@ -905,9 +924,34 @@ __global__ void k_draw_window(const WindowArgs A)
     out[4] = key[1];
     out[5] = key[2];
   }
+  return mine;
+}
+
+__global__ void k_draw_window(const WindowArgs A)
+{
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = A.m0 + o < A.m1;
+  long long out[6] = { 0, 0, 0, 0, 0, 0 };
+  const bool owned = live && draw_window_column(A, o, out);
+  if (A.mb.world > 0)
+  {
+    if (owned)
+      for (int r = 0; r < A.mb.world; ++r)
+      {
+        long long* win = mb_window(A.mb.peer[r], A.mb_parity, A.mb.max_window);
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
-    A.window[(size_t)k * A.stride + o] = out[k];
+        for (int k = 0; k < 6; ++k)
+          win[(size_t)k * (size_t)A.mb.max_window + o] = out[k];
+      }
+    mb_window_done_when_last(A.mb, A.mb_parity, A.mb_gen, A.mb_counter);
+    return;
+  }
+  if (live)
+  {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      A.window[(size_t)k * A.stride + o] = out[k];
+  }
 }
 
 __global__ void k_adopt(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th,
@@ -997,9 +1041,13 @@ __global__ void k_systematic_select(const SystematicArgs A)
 }
 
 // rows 3..5 of an int64 draw window -> three int rows in pinned host memory, then the generation word
-__global__ void k_publish_window_keys(const long long* __restrict__ window, int stride, int n, int* host_keys,
-                                      unsigned* done_counter, volatile unsigned* host_done, unsigned generation)
+// With a mailbox window every block first waits for the "done" words of all shards (kernels_mailbox.hpp).
+__global__ void k_publish_window_keys(const long long* window, int stride, int n, int* host_keys,
+                                      unsigned* done_counter, volatile unsigned* host_done, unsigned generation,
+                                      const MailboxDev M, int wait_parity, unsigned long long wait_gen)
 {
+  if (M.world > 0)
+    mb_block_wait(M, mb_win_done(M.peer[M.rank], wait_parity, 0), wait_gen);
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n)
   {
@@ -1011,8 +1059,11 @@ __global__ void k_publish_window_keys(const long long* __restrict__ window, int 
 }
 
 // rows 3..5 of an int64 draw window -> int key triples (AoS) on the device
-__global__ void k_window_keys_to_aos(const long long* __restrict__ window, int stride, int n, int* __restrict__ keys)
+__global__ void k_window_keys_to_aos(const long long* window, int stride, int n, int* __restrict__ keys,
+                                     const MailboxDev M, int wait_parity, unsigned long long wait_gen)
 {
+  if (M.world > 0)
+    mb_block_wait(M, mb_win_done(M.peer[M.rank], wait_parity, 0), wait_gen);
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n)
   {

@@ -47,9 +47,43 @@ class HipShardBackend:
         p = C.c_void_p()
         engine.check(engine.lib.bpf_shard_scalars_dev(engine.h, C.byref(p)))
         self.scalars = torch.as_tensor(_DevArray(p.value, (16,), "<f8"), device=device)
+        self._total_view, self._sum_view = self.scalars[0:1], self.scalars[7:8]
 
     def n_local(self):
         return self.pf.getState().sample_count
+
+    # ---- mailbox exchange (include/badger_pf.h, bpf_shard_mailbox_*): peer stores over xGMI instead of collectives
+    def mailbox_create(self, rank, world, max_window):
+        """64-byte IPC handle of this engine's mailbox, or None when it cannot be allocated / exported."""
+        buf = (C.c_ubyte * 64)()
+        rc = self.e.lib.bpf_shard_mailbox_create(self.e.h, rank, world, int(max_window), buf)
+        self._mb_world, self._mb_stride, self._mb_views = world, int(max_window), {}
+        return bytes(buf) if rc == 0 else None
+
+    def mailbox_connect(self, handles):
+        """Maps the peers (handles: world x 64 bytes in rank order) and runs one round with all of them."""
+        return self.e.lib.bpf_shard_mailbox_connect(self.e.h, C.c_char_p(handles)) == 0
+
+    def mailbox_destroy(self):
+        self.e.lib.bpf_shard_mailbox_destroy(self.e.h)
+
+    def _mb_view(self, ptr, shape, typestr):
+        v = self._mb_views.get(ptr)
+        if v is None:
+            v = self._mb_views[ptr] = torch.as_tensor(_DevArray(ptr, shape, typestr), device=self.device)
+        return v
+
+    def mailbox_totals(self):
+        """The W totals of the scoring stage just issued (complete once normalize has run: it waits in-kernel)."""
+        p = C.c_void_p()
+        self.e.check(self.e.lib.bpf_shard_mailbox_totals(self.e.h, C.byref(p)))
+        return self._mb_view(p.value, (self._mb_world,), "<f8")
+
+    def mailbox_window(self):
+        """A fresh [6, max_window] int64 window; valid until the next-but-one call."""
+        p, stride = C.c_void_p(), C.c_int()
+        self.e.check(self.e.lib.bpf_shard_mailbox_window(self.e.h, C.byref(p), C.byref(stride)))
+        return self._mb_view(p.value, (6, stride.value), "<i8")
 
     def score(self, data):
         lib, e = self.e.lib, self.e
@@ -75,7 +109,7 @@ class HipShardBackend:
                                                     data.range_count_, data.range_max_, int(global_n)))
 
     def local_total(self):
-        return self.scalars[0:1]
+        return self._total_view
 
     def normalize(self, totals, global_n):
         e = self.e
@@ -85,7 +119,7 @@ class HipShardBackend:
         self.e.check(self.e.lib.bpf_shard_build_cdf(self.e.h, C.c_void_p(flags.data_ptr())))
 
     def local_sum(self):
-        return self.scalars[7:8]
+        return self._sum_view
 
     def draw_window(self, rng, m0, m1, sums, sums_are_totals, rank, world, window, flags):
         e = self.e
@@ -208,13 +242,16 @@ class ShardedState:
 class ShardedFilter:
     """ParticleFilter::updateSensor / updateResample over W shards (see module docstring)."""
 
-    def __init__(self, backend, dist, rank=None, world=None, first_window=4096):
+    def __init__(self, backend, dist, rank=None, world=None, first_window=4096, exchange="auto"):
         self.b = backend
         self.dist = dist
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
         self.device = backend.device
         self.cpu_collectives = dist.get_backend() == "gloo" and torch.device(self.device).type != "cpu"
+        self._nccl = not self.cpu_collectives and dist.get_backend() == "nccl"
+        self._gather_out = {}
+        self._pose_views = {}
         self.max_global = backend.max_samples()  # engines are created with the GLOBAL min / max sample counts
         n = torch.tensor([backend.n_local()], dtype=torch.int64, device=self.device)
         self.counts = [int(v) for v in self._all_gather(n).cpu().tolist()]
@@ -226,16 +263,51 @@ class ShardedFilter:
         self.leaf_count = self.bin_count = 0
         self.windows_used = 0
         self.totals = None  # per-shard weight totals of the last update_sensor (None: weights changed since)
+        # exchange: "mailbox" = peer stores through IPC-mapped device memory (all ranks on one node), "collective" =
+        # torch.distributed all-gather / all-reduce, "auto" = mailbox when every rank could set it up
+        self.mailbox = False
+        if exchange not in ("auto", "mailbox", "collective"):
+            raise ValueError("exchange: auto, mailbox or collective")
+        if exchange != "collective" and hasattr(backend, "mailbox_create") and self.world <= 16:
+            self.mailbox = self._setup_mailbox()
+        if exchange == "mailbox" and not self.mailbox:
+            raise RuntimeError("mailbox exchange requested but not every rank could set it up")
         if backend.resample_model() == 1:
             # the systematic resampler sizes the new set from the leaf count of the CURRENT set's tree, which the
             # reference builds when the set is created (not after motion updates): take it now
             self._global_leaf_count()
 
+    def _all_agree(self, ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        if self.cpu_collectives:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN)
+            return int(h.item()) == 1
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def _setup_mailbox(self):
+        """True when every rank created its mailbox, mapped all the others and completed a round with them."""
+        b = self.b
+        handle = b.mailbox_create(self.rank, self.world, self.max_global)
+        mine = torch.tensor(list(handle if handle is not None else bytes(64)), dtype=torch.uint8, device=self.device)
+        handles = self._all_gather(mine).cpu().numpy().tobytes()
+        ok = self._all_agree(handle is not None)
+        if ok:
+            ok = self._all_agree(b.mailbox_connect(handles))
+        if not ok:
+            b.mailbox_destroy()
+        return ok
+
     # ---- collectives (device tensors with nccl; staged through the host only for gloo + GPU)
     def _all_gather(self, t):
-        if not self.cpu_collectives and self.dist.get_backend() == "nccl":
-            out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
-            self.dist.all_gather_into_tensor(out, t.contiguous())
+        if self._nccl:
+            # one output buffer per shape, reused: the callers consume the result before the next gather of that shape
+            key = (t.numel(), t.dtype)
+            out = self._gather_out.get(key)
+            if out is None:
+                out = self._gather_out[key] = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, t if t.is_contiguous() else t.contiguous())
             return out
         src = t.cpu() if self.cpu_collectives else t
         outs = [torch.empty_like(src) for _ in range(self.world)]
@@ -252,6 +324,29 @@ class ShardedFilter:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
+    def _window(self, key, count):
+        """The [6, >= count] int64 draw window of the next exchange."""
+        if self.mailbox:
+            return self.b.mailbox_window()
+        window = self._windows.get(key)
+        if window is None:
+            window = self._windows[key] = torch.zeros((6, count), dtype=torch.int64, device=self.device)
+        return window
+
+    def _assemble(self, window):
+        """Every shard's columns into every shard's window: nothing to do with a mailbox (the draw kernel stored
+        them into all peers, the window's first consumer waits for them), one integer all-reduce otherwise."""
+        if not self.mailbox:
+            self._all_reduce_sum(window)
+
+    def _pose_rows(self, window):
+        """(x, y, theta) float64 row views of a window buffer; the buffers live in self._windows, so are the views."""
+        v = self._pose_views.get(id(window))
+        if v is None:
+            p = window[0:3].view(torch.float64)
+            v = self._pose_views[id(window)] = (p[0], p[1], p[2], window)  # keeps the buffer alive with its id
+        return v
+
     # ---- motion update (Odom::updateAction): no exchange
     def update_action(self, odom, data):
         first = sum(self.counts[:self.rank])
@@ -264,7 +359,8 @@ class ShardedFilter:
             # prob model with beam skipping: one extra all-reduce of max_beams int32 between its two passes
             self._all_reduce_sum(counts)
             self.b.score_finish(data, self.sample_count)
-        self.totals = self._all_gather(self.b.local_total())
+        # mailbox: the scoring stage has already stored this rank's total into every peer, normalize waits in-kernel
+        self.totals = self.b.mailbox_totals() if self.mailbox else self._all_gather(self.b.local_total())
         self.b.normalize(self.totals, self.sample_count)
 
     def _global_leaf_count(self):
@@ -295,23 +391,20 @@ class ShardedFilter:
             sums, sums_are_totals = self.totals, True
         else:
             sums, sums_are_totals = self._all_gather(b.local_sum()), False
-        window = self._windows.get((count, "sys"))
-        if window is None:
-            window = torch.zeros((6, count), dtype=torch.int64, device=self.device)
-            self._windows[(count, "sys")] = window
+        window = self._window((count, "sys"), count)
         b.systematic_window(rng, count, sums, sums_are_totals, self.rank, W, window, self.flags)
-        self._all_reduce_sum(window)
+        self._assemble(window)
         b.kld_reset()
         b.kld_insert_window(window, count)  # the tree of the new set: every sample, no stop rule
         leaf, bins = b.kld_counts()
         M = count
         lo, hi = (M * self.rank) // W, (M * (self.rank + 1)) // W
-        pose = window[0:3].view(torch.float64)
+        pose = self._pose_rows(window)
         if M <= 8192:
             b.tail_small(pose[0], pose[1], pose[2], M, lo, hi, leaf, bins)
         else:
-            b.adopt(pose[0, lo:hi], pose[1, lo:hi], pose[2, lo:hi], hi - lo, M, leaf, bins)
-            b.converged(pose[0, :M], pose[1, :M], M)
+            b.adopt(pose[0][lo:hi], pose[1][lo:hi], pose[2][lo:hi], hi - lo, M, leaf, bins)
+            b.converged(pose[0][:M], pose[1][:M], M)
         b.set_rng_state(b.end_resample(M))
         self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
         self.sample_count = M
@@ -344,12 +437,9 @@ class ShardedFilter:
             if m0 > 0 and self.max_global - m0 >= device_min:
                 # no stop in the first window and a long stream ahead (a spread cloud): one window with every
                 # remaining candidate, and the ordered kd-tree replay runs on the device (every rank, redundantly)
-                whole = self._windows.get("whole")
-                if whole is None:
-                    whole = torch.zeros((6, self.max_global), dtype=torch.int64, device=self.device)
-                    self._windows["whole"] = whole
+                whole = self._window("whole", self.max_global)
                 b.draw_window(rng, 0, self.max_global, sums, sums_are_totals, self.rank, W, whole, self.flags)
-                self._all_reduce_sum(whole)
+                self._assemble(whole)
                 handled, dstop, dleaf, dbins = b.kld_stop_window(whole, self.max_global)
                 self.windows_used += 1
                 if handled:
@@ -360,13 +450,14 @@ class ShardedFilter:
                 device_min = 1 << 62  # this stream is outside what the device tree takes: host replay
             m1 = min(self.max_global, m0 + win)
             cnt = m1 - m0
-            window = self._windows.get((cnt, len(windows)))
-            if window is None:
-                window = torch.zeros((6, cnt), dtype=torch.int64, device=self.device)
-                self._windows[(cnt, len(windows))] = window
+            window = self._window((cnt, len(windows)), cnt)
             b.draw_window(rng, m0, m1, sums, sums_are_totals, self.rank, W, window, self.flags)
-            self._all_reduce_sum(window)
+            self._assemble(window)
             stop = b.kld_feed_window(window, cnt, m0)  # the one host wait of the window
+            if self.mailbox and stop < 0:
+                # a mailbox window is overwritten two exchanges later: keep its poses now, the stream goes on
+                self.out[:, m0:m0 + cnt] = window[0:3, :cnt].view(torch.float64)
+                window = None
             windows.append((m0, cnt, window))
             self.windows_used += 1
             m0 = m1
@@ -374,13 +465,14 @@ class ShardedFilter:
         M = stop if stop > 0 else self.max_global
         leaf, bins = device_counts if device_counts is not None else b.kld_counts()
         lo, hi = (M * self.rank) // W, (M * (self.rank + 1)) // W
-        if len(windows) == 1 and M <= 8192:
+        if len(windows) == 1 and M <= 8192 and windows[0][2] is not None:
             # the common case: one window, small set -> adopt + weights + updateConverged in one launch
-            pose = windows[0][2][0:3].view(torch.float64)
+            pose = self._pose_rows(windows[0][2])
             b.tail_small(pose[0], pose[1], pose[2], M, lo, hi, leaf, bins)
         else:
             for (w0, cnt, window) in windows:
-                self.out[:, w0:w0 + cnt] = window[0:3].view(torch.float64)
+                if window is not None:
+                    self.out[:, w0:w0 + cnt] = window[0:3, :cnt].view(torch.float64)
             b.adopt(self.out[0, lo:hi], self.out[1, lo:hi], self.out[2, lo:hi], hi - lo, M, leaf, bins)
             b.converged(self.out[0, :M], self.out[1, :M], M)
         b.set_rng_state(b.end_resample(M))

@@ -15,6 +15,7 @@ each rank holds a 100 000-particle shard of one filter (weak scaling).
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -274,7 +275,8 @@ def main():
     if dist is not None:
         from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
         backend = HipShardBackend(e, sc, pf, torch.device("cuda", local_rank))
-        sf = ShardedFilter(backend, dist)
+        # BPF_SHARD_EXCHANGE=collective forces the RCCL all-gather / all-reduce; default: mailbox when every rank can
+        sf = ShardedFilter(backend, dist, exchange=os.environ.get("BPF_SHARD_EXCHANGE", "auto"))
         shard_counts = list(sf.counts)
         shard_leaf = sf.leaf_count  # global leaf count of the initial set (systematic resampler)
 
@@ -304,6 +306,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Everything alive now (torch, numpy, the engine wrappers) goes to the permanent generation: a full collection of
+    # the interpreter's ~1e6 module objects costs 45-60 ms and would otherwise land inside the timed region every
+    # few hundred steps (measured: one 50 ms step in 230 on the sharded path).  The collector stays enabled.
+    gc.collect()
+    gc.freeze()
     e.profile_enable(1)  # HIP events around the scoring kernel only (2 event records per step)
     e.profile_reset()
     t0 = time.perf_counter()
@@ -381,7 +388,9 @@ def main():
                                                                                args.map_size, args.map_size)),
                        "cloud": args.cloud, "resampler": args.resampler, "motion": args.motion, "particles_per_gpu": wl["n"],
                        "particles_total": n_total, "resampled_to": int(st.sample_count),
-                       "kld_leaf_count": int(st.leaf_count), "parallelism": "particle-shard x%d" % world},
+                       "kld_leaf_count": int(st.leaf_count), "parallelism": "particle-shard x%d" % world,
+                       "shard_exchange": (None if dist is None else ("mailbox (xGMI peer stores)" if sf.mailbox
+                                                                     else "collective (RCCL)"))},
             "roofline": {"bound": "hbm", "kernel": e.score_kernel_name(), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,

@@ -42,7 +42,8 @@ enum
   BPF_ERR_CDF_MISS = 5,           /* reference ROS_ASSERT(i < sample_count), particle_filter.cpp:399 */
   BPF_ERR_LUT_LEVELS = 6,         /* distance LUT holds more than 8190 distinct values */
   BPF_ERR_BEAM_STEP = 7,          /* beam model with range_count < max_beams: the reference never returns */
-  BPF_ERR_CAPACITY = 8
+  BPF_ERR_CAPACITY = 8,
+  BPF_ERR_EXCHANGE = 9            /* mailbox exchange: a peer's word did not arrive within 5 s */
 };
 
 enum
@@ -385,6 +386,30 @@ int bpf_pf_resample_limit(bpf_engine* e, int leaf_count, int* count_out);
 int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int count, const void* sums_dev,
                                     int sums_are_totals, int rank, int world, void* window_dev, int stride,
                                     void* flags_dev);
+/* Mailbox exchange: the two small exchanges of the sharded path (W weight totals; one draw window whose every
+ * column has exactly one writer) without a collective library.  Every engine of the node owns one uncached device
+ * allocation, exported by IPC handle and mapped by the W - 1 others; a producer kernel stores its values into the
+ * same slot of every peer's mailbox over xGMI and then a generation word (system-scope release), a consumer kernel
+ * waits on the words in its own mailbox (bounded: 5 s, then BPF_ERR_EXCHANGE at the next host check).  The post
+ * rides on the kernel that produces the value and the wait on the kernel that consumes it: no extra launch and no
+ * host round trip.  Stands where torch.distributed / RCCL all-gather + all-reduce would (badger_amcl_amd/sharded.py
+ * falls back to those when a mailbox cannot be set up); there is no counterpart in the reference.
+ *   create   allocates for windows of up to max_window draws and returns the 64-byte IPC handle;
+ *   connect  takes the world x 64 bytes of all ranks' handles in rank order (gather them with any host-side
+ *            transport), maps the peers and runs one post-and-wait round with all of them -- every rank must call
+ *            it at about the same time; BPF_ERR_EXCHANGE when a peer does not answer;
+ *   totals   after a sharded scoring stage (which posted this rank's total): device pointer to the W totals of this
+ *            update, to be passed as totals_dev / sums_dev -- bpf_shard_normalize_dev then waits for them in-kernel;
+ *   window   a fresh [6][stride] int64 window for the next exchange: bpf_shard_draw_window_dev /
+ *            bpf_shard_systematic_window_dev given this pointer store every owned column into all peers' copies, and
+ *            the first consumer (bpf_kld_feed_dev / bpf_kld_insert_dev / bpf_kld_stop_dev) waits for all shards.
+ *            The window stays valid until the next-but-one call; copy out what has to live longer. */
+#define BPF_MAILBOX_HANDLE_BYTES 64
+int bpf_shard_mailbox_create(bpf_engine* e, int rank, int world, long long max_window, void* handle_out);
+int bpf_shard_mailbox_connect(bpf_engine* e, const void* handles);
+int bpf_shard_mailbox_destroy(bpf_engine* e);
+int bpf_shard_mailbox_totals(bpf_engine* e, void** totals_dev);
+int bpf_shard_mailbox_window(bpf_engine* e, void** window_dev, int* stride);
 /* insert every key of the window into the engine's histogram tree (no stop rule): the tree of a systematic
  * resample, or of an initial set (keys as bpf_kld_feed / bpf_kld_feed_dev take them) */
 int bpf_kld_insert(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys);

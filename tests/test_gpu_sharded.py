@@ -1,6 +1,8 @@
-"""GPU test of the sharded path: two ranks share cuda:0 (gloo carries the exchanges, staged
-through the host), each drives the bpf_shard_* stage functions on its half of the set; together
-they must reproduce the single-engine result, which the other gpu tests tie to the oracle."""
+"""GPU test of the sharded path: two ranks share cuda:0, each drives the bpf_shard_* stage functions on its half of
+the set; together they must reproduce the single-engine result, which the other gpu tests tie to the oracle.  The
+exchanges run both ways: through the mailbox (peer stores into IPC-mapped device memory, here two processes on one
+GPU; include/badger_pf.h bpf_shard_mailbox_*) and as collectives (gloo, staged through the host).  The remaining
+host-side exchanges (set-up, beam-skip counts) always use gloo."""
 import os
 import socket
 import sys
@@ -31,7 +33,7 @@ def _scenario(cloud="converged"):
     return orc, Scenario(orc, size=400, n=6000, beams=181, cloud=cloud)
 
 
-def _worker(rank, world, port, out_dir, cloud, device_min, resampler):
+def _worker(rank, world, port, out_dir, cloud, device_min, resampler, exchange):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -54,7 +56,8 @@ def _worker(rank, world, port, out_dir, cloud, device_min, resampler):
     pf.setResampleModel(resampler)
     b = HipShardBackend(e, scn, pf, torch.device("cuda", 0))
     b.kld_device_min = device_min
-    sf = ShardedFilter(b, dist, first_window=1024)
+    sf = ShardedFilter(b, dist, first_window=1024, exchange=exchange)
+    assert sf.mailbox == (exchange == "mailbox")
     od = bpf.Odom(e)
     od.setModel(*ODOM)
     recs = []
@@ -73,15 +76,16 @@ def _worker(rank, world, port, out_dir, cloud, device_min, resampler):
     e.close()
 
 
+@pytest.mark.parametrize("exchange", ["mailbox", "collective"])
 @pytest.mark.parametrize("cloud,device_min,resampler", [("converged", 8192, 0), ("spread", 512, 0),
                                                         ("converged", 8192, 1)])
-def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min, resampler):
+def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min, resampler, exchange):
     """converged: early KLD stop inside the first window (host replay).  spread with a low device threshold: no
     stop in the first window, so one window with the whole stream follows and the stop rule runs on the device."""
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), cloud, device_min, resampler), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), cloud, device_min, resampler, exchange), nprocs=2, join=True)
     recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
 
     import badger_amcl_amd as bpf
@@ -142,6 +146,7 @@ def _cloud_worker(rank, world, port, out_dir):
     pf.srand48(5)
     pf.initWithSamples(np.ascontiguousarray(s[lo:hi]))
     sf = ShardedFilter(HipShardBackend(e, sc, pf, torch.device("cuda", 0)), dist, first_window=1024)
+    assert sf.mailbox  # "auto": both ranks can map each other's mailbox, so the exchanges go through it
     sf.update_sensor(bpf.PointCloudData(pts))
     w_after = pf.getCurrentSet().samples.copy()
     sf.update_resample()
@@ -224,6 +229,7 @@ def _beamskip_worker(rank, world, port, out_dir):
     shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
     m, scn, pf, data = shard.gpu_objects(e, 60, "prob", min_samples=100, max_samples=n, seed=3, model_kw=BEAMSKIP)
     sf = ShardedFilter(HipShardBackend(e, scn, pf, torch.device("cuda", 0)), dist, first_window=1024)
+    assert sf.mailbox  # "auto": both ranks can map each other's mailbox, so the exchanges go through it
     recs = []
     for cycle in range(2):
         sf.update_sensor(data)
@@ -299,6 +305,7 @@ def _recovery_worker(rank, world, port, out_dir, resampler):
     pf.setResampleModel(resampler)
     pf.setRandomPoseGenerator(hpf.RANDOM_POSE_FREE_SPACE_2D)
     sf = ShardedFilter(HipShardBackend(e, scn, pf, torch.device("cuda", 0)), dist, first_window=1024)
+    assert sf.mailbox  # "auto": both ranks can map each other's mailbox, so the exchanges go through it
     recs = []
     for cycle in range(3):
         sf.update_sensor(bpf.PlanarData(_recovery_scan(sc, cycle), sc.angles, sc.range_max))
