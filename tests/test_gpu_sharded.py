@@ -352,3 +352,78 @@ def test_two_ranks_recovery_random_poses(tmp_path, resampler):
         assert np.array_equal(merged[:, :3], cur[:, :3])
     assert max(w_diffs) > 0.01
     e.close()
+
+
+STRESS_CYCLES = 16
+
+
+def _stress_worker(rank, world, port, out_dir):
+    """Many cycles with the two ranks deliberately out of step on the host (sleeps of a different length per rank
+    and cycle, before the sensor update and before the resample), so that one rank's kernels regularly sit in a
+    mailbox wait while the other has not even issued its post, and the fast rank runs a whole exchange ahead."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import badger_amcl_amd as bpf
+    from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+    from scenario import Scenario
+    orc, sc = _scenario("converged")
+    n = sc.samples.shape[0]
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    e = bpf.Engine(0)
+    shard = Scenario.__new__(Scenario)
+    shard.__dict__.update(sc.__dict__)
+    shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
+    m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    sf = ShardedFilter(HipShardBackend(e, scn, pf, torch.device("cuda", 0)), dist, first_window=1024,
+                       exchange="mailbox")
+    od = bpf.Odom(e)
+    od.setModel(*ODOM)
+    rs = np.random.RandomState(100 + rank)
+    recs = []
+    for cycle in range(STRESS_CYCLES):
+        sf.update_action(od, bpf.OdomData(*ODATA))
+        time.sleep(float(rs.uniform(0.0, 0.004)) if (cycle + rank) % 3 else 0.0)
+        sf.update_sensor(data)
+        time.sleep(float(rs.uniform(0.0, 0.004)) if (cycle + rank) % 2 else 0.0)
+        sf.update_resample()
+        st = sf.state()
+        recs.append(dict(samples=pf.getCurrentSet().samples.copy(), M=st.sample_count, leaf=st.leaf_count,
+                         rng=pf.getRngState(), miss=st.cdf_miss))
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(recs, dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    e.close()
+
+
+def test_mailbox_exchange_with_ranks_out_of_step(tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_stress_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
+    import badger_amcl_amd as bpf
+    orc, sc = _scenario("converged")
+    n = sc.samples.shape[0]
+    e = bpf.Engine(0)
+    m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    od = bpf.Odom(e)
+    od.setModel(*ODOM)
+    for cycle in range(STRESS_CYCLES):
+        od.updateAction(pf, bpf.OdomData(*ODATA))
+        scn.updateSensor(pf, data)
+        pf.updateResample()
+        st = pf.getState()
+        r0, r1 = recs[0][cycle], recs[1][cycle]
+        for r in (r0, r1):
+            assert r["M"] == st.sample_count and r["leaf"] == st.leaf_count and r["rng"] == pf.getRngState()
+            assert not r["miss"]
+        merged = np.concatenate([r0["samples"], r1["samples"]])
+        assert np.array_equal(merged[:, :3], pf.getCurrentSet().samples[:, :3]), cycle
+    e.close()
