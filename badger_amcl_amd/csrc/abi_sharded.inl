@@ -23,8 +23,16 @@ int shard_local_total(bpf_engine* e)
   {
     // the scoring kernel left per-block partials: one small launch folds them into the local total
     ProfScope ps(e, BPF_K_REDUCE);
-    // with a mailbox the same launch stores the total into every peer's memory
-    const unsigned long long gen = e->mb.active ? ++e->mb.tot_gen : 0;
+    if (e->mb.active)
+    {
+      // mailbox: the fold and the post to the peers ride on the normalise launch that has to follow anyway
+      // (bpf_shard_normalize_dev with bpf_shard_mailbox_totals); one launch less on the critical path
+      ++e->mb.tot_gen;
+      e->mb.fold_deferred = e->fused_partials;
+      e->fused_partials = 0;
+      return BPF_OK;
+    }
+    const unsigned long long gen = 0;
     hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
                        e->fused_partials, e->d_scalars.p, 0, mailbox_dev(e), (int)(gen & 1), gen);
     HIPCHK(e, hipGetLastError());
@@ -125,17 +133,48 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
   HIPCHK(e, e->d_tile_sums.reserve((size_t)nb));
   // totals that are this engine's mailbox slots: the kernel itself waits for the peers' posts of this update
   MailboxDev wait{};
+  const double* fold = nullptr;
+  int n_fold = 0;
   if (mailbox_owns(e, totals_dev))
   {
     if (world != e->mb.world)
       return e->fail(BPF_ERR_INVALID_ARGUMENT, "mailbox totals: world differs from the mailbox's");
-    wait = mailbox_dev(e);
+    if (nb <= kMailboxFusedWaitBlocks)
+    {
+      wait = mailbox_dev(e);
+      if (e->mb.fold_deferred > 0)
+      {
+        fold = e->d_block_partials.p;
+        n_fold = e->mb.fold_deferred;
+        e->mb.fold_deferred = 0;
+      }
+    }
+    else
+    {
+      // a large normalise grid does not spin: fold + post and the wait get small launches of their own
+      if (e->mb.fold_deferred > 0)
+        hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
+                           e->mb.fold_deferred, e->d_scalars.p, 0, mailbox_dev(e), (int)(e->mb.tot_gen & 1),
+                           e->mb.tot_gen);
+      e->mb.fold_deferred = 0;
+      hipLaunchKernelGGL(k_mailbox_wait, dim3(1), dim3(64), 0, e->stream, mailbox_dev(e), 0, (int)(e->mb.tot_gen & 1),
+                         e->mb.tot_gen);
+      HIPCHK(e, hipGetLastError());
+    }
+  }
+  else if (e->mb.fold_deferred > 0)
+  {
+    // the caller normalises with totals of its own: the peers still expect this rank's post of the update
+    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
+                       e->mb.fold_deferred, e->d_scalars.p, 0, mailbox_dev(e), (int)(e->mb.tot_gen & 1), e->mb.tot_gen);
+    HIPCHK(e, hipGetLastError());
+    e->mb.fold_deferred = 0;
   }
   ProfScope ps(e, BPF_K_NORMALIZE);
   hipLaunchKernelGGL(k_normalize_gathered, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
                      static_cast<const double*>(totals_dev), world, global_sample_count, e->d_scalars.p,
                      e->alpha_slow, e->alpha_fast, e->d_tile_sums.p, wait, (int)(e->mb.tot_gen & 1),
-                     e->mb.tot_gen);
+                     e->mb.tot_gen, fold, n_fold);
   HIPCHK(e, hipGetLastError());
   e->tile_sums_n = n;
   return BPF_OK;
@@ -172,13 +211,17 @@ int shard_window_exchange(bpf_engine* e, const void* window_dev, int count, int 
   return BPF_OK;
 }
 
-// wait arguments for the first kernel that reads an exchanged window (gen 0 / world 0: nothing to wait for)
-MailboxDev shard_window_wait(bpf_engine* e, const void* window_dev)
+// wait arguments for the first kernel that reads an exchanged window (world 0: nothing to wait for); a consumer
+// with a large grid gets a one-block wait kernel in front instead of spinning with all its blocks
+MailboxDev shard_window_wait(bpf_engine* e, const void* window_dev, int consumer_blocks)
 {
   if (mailbox_owns(e, window_dev) && e->mb.win_wait)
   {
     e->mb.win_wait = false;
-    return mailbox_dev(e);
+    if (consumer_blocks <= kMailboxFusedWaitBlocks)
+      return mailbox_dev(e);
+    hipLaunchKernelGGL(k_mailbox_wait, dim3(1), dim3(64), 0, e->stream, mailbox_dev(e), 1, (int)(e->mb.win_gen & 1),
+                       e->mb.win_gen);
   }
   return MailboxDev{};
 }
@@ -364,7 +407,7 @@ int bpf_kld_feed_dev(bpf_engine* e, const void* window_dev, int stride, int n_ke
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, e->h_keys.reserve((size_t)n_keys * 3));
   const unsigned generation = ++e->done_generation;
-  const MailboxDev wait = shard_window_wait(e, window_dev);
+  const MailboxDev wait = shard_window_wait(e, window_dev, blocks_for(n_keys, 256));
   hipLaunchKernelGGL(k_publish_window_keys, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
                      static_cast<const long long*>(window_dev), stride, n_keys, e->h_keys.p,
                      reinterpret_cast<unsigned*>(e->d_flags.p + 4), reinterpret_cast<volatile unsigned*>(e->h_done.p),
@@ -561,7 +604,7 @@ int bpf_kld_insert_dev(bpf_engine* e, const void* window_dev, int stride, int n_
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, e->h_keys.reserve((size_t)n_keys * 3));
   const unsigned generation = ++e->done_generation;
-  const MailboxDev wait = shard_window_wait(e, window_dev);
+  const MailboxDev wait = shard_window_wait(e, window_dev, blocks_for(n_keys, 256));
   hipLaunchKernelGGL(k_publish_window_keys, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
                      static_cast<const long long*>(window_dev), stride, n_keys, e->h_keys.p,
                      reinterpret_cast<unsigned*>(e->d_flags.p + 4), reinterpret_cast<volatile unsigned*>(e->h_done.p),
@@ -584,7 +627,7 @@ int bpf_kld_stop_dev(bpf_engine* e, const void* window_dev, int stride, int n_ke
     return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, e->d_keys.reserve((size_t)n_keys * 3));
-  const MailboxDev wait = shard_window_wait(e, window_dev);
+  const MailboxDev wait = shard_window_wait(e, window_dev, blocks_for(n_keys, 256));
   hipLaunchKernelGGL(k_window_keys_to_aos, dim3(blocks_for(n_keys, 256)), dim3(256), 0, e->stream,
                      static_cast<const long long*>(window_dev), stride, n_keys, e->d_keys.p, wait,
                      (int)(e->mb.win_gen & 1), e->mb.win_gen);

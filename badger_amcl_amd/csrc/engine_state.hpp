@@ -272,6 +272,7 @@ struct bpf_engine
     unsigned long long win_gen = 0; // generation of the window handed out last
     bool win_wait = false;          // that window's columns are in flight: its first consumer kernel has to wait
     unsigned long long hello = 0;
+    int fold_deferred = 0;          // > 0: that many scoring partials wait to be folded and posted by the normalise launch
   } mb;
   PinnedBuf<unsigned> h_mb_error;
   PinnedBuf<int> h_mb_result;

@@ -356,8 +356,10 @@ int resample_multinomial(bpf_engine* e, double w_diff)
     A.chain = chain;
     A.free_space = free_space;
     A.guide = e->cdf_guide_valid ? e->d_cdf_guide.p : nullptr;
-    // long stream ahead: either the first window found no stop, or the previous cycle ran to the end
-    const bool long_stream = (m0 > 0 || e->window_hint >= maxs) && maxs - m0 >= e->kld_device_min;
+    // long stream ahead: the previous cycle ran to the end, or the windows so far found no stop and the bound for
+    // the leaves seen so far (a lower estimate of where the stop will be) is still far away
+    const bool long_stream = (m0 > 0 ? cached_limit - m0 >= e->kld_device_min : e->window_hint >= maxs) &&
+                             maxs - m0 >= e->kld_device_min;
     if (long_stream && !device_declined)
     {
       // no stop inside the first window and a long stream ahead (a spread cloud): the ordered replay moves
@@ -428,7 +430,9 @@ int resample_multinomial(bpf_engine* e, double w_diff)
       }
     }
     m0 = m1;
-    window *= 4;
+    // next window: up to a quarter past the bound for the leaves seen so far
+    const int need = cached_limit - m0;
+    window = std::max(1024, (need + need / 4 + 1023) / 1024 * 1024);
   }
   const int M = (stop > 0) ? stop : maxs;
   // the window that found the stop also inserted nothing past it: hist is exactly set b's tree

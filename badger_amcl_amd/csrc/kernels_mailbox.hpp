@@ -27,6 +27,7 @@ namespace bpf
 constexpr int kMailboxMaxWorld = 16;
 constexpr size_t kMailboxHeader = 4096;
 constexpr long long kMailboxTimeoutTicks = 500000000ll;  // 5 s of the 100 MHz wall clock
+constexpr int kMailboxFusedWaitBlocks = 64;               // consumers with more blocks get k_mailbox_wait in front
 
 struct MailboxDev
 {
@@ -117,6 +118,14 @@ __device__ __forceinline__ void mb_window_done_when_last(const MailboxDev& M, in
 __global__ void k_mailbox_post_total(const double* value, const MailboxDev M, int parity, unsigned long long gen)
 {
   mb_post_total(M, parity, gen, *value);
+}
+
+// A wait of its own (one block) in front of a consumer whose grid is large: hundreds of blocks spinning on the
+// words would hold the whole GPU for the length of the wait (and, where several ranks share one GPU, keep the very
+// kernel they are waiting for from being scheduled).  which: 0 = totals words, 1 = window "done" words.
+__global__ void k_mailbox_wait(const MailboxDev M, int which, int parity, unsigned long long gen)
+{
+  mb_block_wait(M, which == 0 ? mb_tot_gen(M.peer[M.rank], parity, 0) : mb_win_done(M.peer[M.rank], parity, 0), gen);
 }
 
 // connect-time self-test: one full round (post to every peer, wait for every peer); result[0] = 1 when all arrived

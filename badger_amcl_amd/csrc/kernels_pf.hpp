@@ -342,11 +342,28 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered(double* __
                                                                      double alpha_slow, double alpha_fast,
                                                                      double* __restrict__ tile_sums,
                                                                      const MailboxDev M, int wait_parity,
-                                                                     unsigned long long wait_gen)
+                                                                     unsigned long long wait_gen,
+                                                                     const double* __restrict__ fold_partials,
+                                                                     int n_fold)
 {
   __shared__ double s_wave[4];
-  if (M.world > 0)  // `totals` are this rank's mailbox slots: wait until every peer's total of this update is in
+  if (M.world > 0)
+  {
+    // `totals` are this rank's mailbox slots.  When the scoring stage left its fold to this launch, block 0 does
+    // what k_fold_partials does (same summation shape) and posts the total to every peer, itself included ...
+    if (fold_partials != nullptr && blockIdx.x == 0)
+    {
+      double acc = 0.0;
+      for (int i = threadIdx.x; i < n_fold; i += BPF_RED_BLOCK)
+        acc += fold_partials[i];
+      const double tot = block_sum_256(acc, s_wave);
+      if (threadIdx.x == 0)
+        sc->v[0] = tot;
+      mb_post_total(M, wait_parity, wait_gen, tot);
+    }
+    // ... then every block waits until all peers' totals of this update are in
     mb_block_wait(M, mb_tot_gen(M.peer[M.rank], wait_parity, 0), wait_gen);
+  }
   double total = 0.0;
   for (int r = 0; r < world; ++r)
     total += totals[r];

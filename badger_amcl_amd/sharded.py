@@ -433,8 +433,9 @@ class ShardedFilter:
         device_min = b.kld_device_min
         if win > 4096 and self.max_global - 4096 >= device_min:
             win = 4096  # keep the host's first window short when the device tree can take over after it
+        need = 0  # after a window without a stop: draws still missing to the bound for the leaves seen so far
         while m0 < self.max_global and stop < 0:
-            if m0 > 0 and self.max_global - m0 >= device_min:
+            if m0 > 0 and self.max_global - m0 >= device_min and need >= device_min:
                 # no stop in the first window and a long stream ahead (a spread cloud): one window with every
                 # remaining candidate, and the ordered kd-tree replay runs on the device (every rank, redundantly)
                 whole = self._window("whole", self.max_global)
@@ -461,7 +462,10 @@ class ShardedFilter:
             windows.append((m0, cnt, window))
             self.windows_used += 1
             m0 = m1
-            win *= 4
+            if stop < 0:
+                # next window: up to a quarter past the bound for the leaves seen so far (a lower estimate of the stop)
+                need = b.resample_limit(b.kld_counts()[0]) - m0
+                win = max(1024, (need + need // 4 + 1023) // 1024 * 1024)
         M = stop if stop > 0 else self.max_global
         leaf, bins = device_counts if device_counts is not None else b.kld_counts()
         lo, hi = (M * self.rank) // W, (M * (self.rank + 1)) // W

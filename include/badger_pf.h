@@ -398,8 +398,10 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
  *   connect  takes the world x 64 bytes of all ranks' handles in rank order (gather them with any host-side
  *            transport), maps the peers and runs one post-and-wait round with all of them -- every rank must call
  *            it at about the same time; BPF_ERR_EXCHANGE when a peer does not answer;
- *   totals   after a sharded scoring stage (which posted this rank's total): device pointer to the W totals of this
- *            update, to be passed as totals_dev / sums_dev -- bpf_shard_normalize_dev then waits for them in-kernel;
+ *   totals   after a sharded scoring stage: device pointer to the W totals of this update, to be passed as
+ *            totals_dev / sums_dev.  This rank's total is posted to the peers by the scoring stage or, for the field
+ *            models, by the bpf_shard_normalize_dev launch that must follow (it folds the scoring kernel's partials,
+ *            posts, and then waits in-kernel for all W totals);
  *   window   a fresh [6][stride] int64 window for the next exchange: bpf_shard_draw_window_dev /
  *            bpf_shard_systematic_window_dev given this pointer store every owned column into all peers' copies, and
  *            the first consumer (bpf_kld_feed_dev / bpf_kld_insert_dev / bpf_kld_stop_dev) waits for all shards.
