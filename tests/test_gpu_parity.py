@@ -199,6 +199,41 @@ def test_kld_stop_rule_on_device_matches_oracle(engine, orc, cloud, n, pop):
         engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 8192)
 
 
+def test_stop_beyond_the_first_window_takes_sized_follow_up_windows(engine, orc):
+    """First a resample with a loose KLD bound (pop_err 0.05: a set of ~130, so the next resample starts with the
+    minimum window of 1024 draws), then the default bound on the full cloud again, whose stop lies near 1900 draws,
+    with the device tree switched off: the host replay goes on through a follow-up window sized from the bound for
+    the leaves seen so far.  Exact against the oracle."""
+    import badger_amcl_amd.pf as hpf
+    sc_ = Scenario(orc, size=400, n=20000, beams=61, cloud="converged")
+    engine.set_option(hpf.OPT_CDF_SERIAL, 1)
+    engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 0)  # 0 = never
+    try:
+        m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf", min_samples=100, seed=5)
+        pf.setPopulationSizeParameters(0.05, 0.99)
+        sc.updateSensor(pf, data)
+        pf.updateResample()
+        assert pf.getState().sample_count < 800
+        pf.setPopulationSizeParameters(0.01, 3.0)
+        pf.initWithSamples(sc_.samples)
+        sc.updateSensor(pf, data)
+        before, st0, rng0 = pf.getCurrentSet(), pf.getState(), pf.getRngState()
+        pf.updateResample()
+        after, st1 = pf.getCurrentSet(), pf.getState()
+        opf = orc.ParticleFilter(100, 20000, 0.0, 0.0, 85.0)
+        opf.pf.rng = rng0
+        opf.set_samples(before.samples, leaf_count=st0.leaf_count)
+        out = opf.update_resample()
+        assert out.status == 0 and out.sample_count > 1024
+        assert st1.resample_windows == 2 and st1.kld_on_device == 0
+        assert st1.sample_count == out.sample_count and st1.leaf_count == out.leaf_count
+        assert np.array_equal(after.samples[:, :3], opf.samples[:out.sample_count, :3])
+        assert pf.getRngState() == opf.pf.rng
+    finally:
+        engine.set_option(hpf.OPT_CDF_SERIAL, 0)
+        engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 8192)
+
+
 def test_resample_kld_parameters_and_second_cycle(engine, orc):
     """Launch-file KLD parameters (kld_err .0025 passed as pop_err, kld_z .9975 as pop_z) and two
     full update+resample cycles, the second starting from the resampled set."""
