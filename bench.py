@@ -218,8 +218,8 @@ def cpu_baseline_all_cores(args, wl, lut):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--model", default="lf", choices=["lf", "gompertz", "beam", "cloud3d"])
     ap.add_argument("--cloud", default="converged", choices=["converged", "spread"])
     ap.add_argument("--resampler", default="multinomial", choices=["multinomial", "systematic"])
@@ -309,14 +309,16 @@ def main():
         e.synchronize()
         torch.cuda.synchronize()
 
+    # Everything alive now (torch, numpy, the engine wrappers) goes to the permanent generation: a full collection of
+    # the interpreter's ~1e6 module objects costs 45-60 ms and would otherwise land inside the timed region every
+    # few hundred steps (measured: one 50 ms step in 230 on the sharded path).  The collector stays enabled.  Done
+    # BEFORE the warm-up: a pause of that length right in front of the timed region lets the GPU's clocks fall, and
+    # the first ~50 steps then run the scoring kernel at 80 us instead of 74-75.
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     fence()
-    # Everything alive now (torch, numpy, the engine wrappers) goes to the permanent generation: a full collection of
-    # the interpreter's ~1e6 module objects costs 45-60 ms and would otherwise land inside the timed region every
-    # few hundred steps (measured: one 50 ms step in 230 on the sharded path).  The collector stays enabled.
-    gc.collect()
-    gc.freeze()
     e.profile_enable(1)  # HIP events around the scoring kernel only (2 event records per step)
     e.profile_reset()
     t0 = time.perf_counter()
