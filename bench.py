@@ -268,6 +268,8 @@ def main():
 
     wl = build_workload(args, rank)
     wl["world"] = world
+    gc.collect()
+    gc.freeze()  # see the comment at the warm-up loop
     e, m, sc, pf, data, lut = setup_engine(args, wl, local_rank)
 
     odom = odata = None
@@ -313,9 +315,8 @@ def main():
     # the interpreter's ~1e6 module objects costs 45-60 ms and would otherwise land inside the timed region every
     # few hundred steps (measured: one 50 ms step in 230 on the sharded path).  The collector stays enabled.  Done
     # BEFORE the warm-up: a pause of that length right in front of the timed region lets the GPU's clocks fall, and
-    # the first ~50 steps then run the scoring kernel at 80 us instead of 74-75.
-    gc.collect()
-    gc.freeze()
+    # the first ~50 steps then run the scoring kernel at 80 us instead of 74-75.  (It is done above, before the engine
+    # is set up.)
     for _ in range(args.warmup):
         step()
     fence()
