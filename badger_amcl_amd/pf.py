@@ -184,6 +184,13 @@ class PlanarData:
         self.angles_ = np.ascontiguousarray(angles, dtype=np.float64)
         self.range_count_ = int(self.ranges_.shape[0])
         self.range_max_ = float(range_max)
+        self._ptr_of = None
+
+    def pointers(self):
+        """(ranges, angles) as C pointers; formed once per pair of arrays (numpy's ctypes view costs ~2 us a time)."""
+        if self._ptr_of is None or self._ptr_of[0] is not self.ranges_ or self._ptr_of[1] is not self.angles_:
+            self._ptr_of = (self.ranges_, self.angles_, _dp(self.ranges_), _dp(self.angles_))
+        return self._ptr_of[2], self._ptr_of[3]
 
 
 class PFSampleSet:
@@ -400,8 +407,8 @@ class PlanarScanner:
         """PlanarScanner::updateSensor(pf, data): false (and no effect) when max_beams < 2."""
         if self.max_beams < 2:
             return False
-        self.e.check(self.e.lib.bpf_pf_update_sensor_planar(self.e.h, _dp(data.ranges_), _dp(data.angles_),
-                                                            data.range_count_, data.range_max_))
+        rp, ap = data.pointers()
+        self.e.check(self.e.lib.bpf_pf_update_sensor_planar(self.e.h, rp, ap, data.range_count_, data.range_max_))
         return True
 
     def applyModelToSampleSet(self, data, samples, set_converged=0):

@@ -91,9 +91,8 @@ class HipShardBackend:
             e.check(lib.bpf_shard_score_cloud(e.h, data.points_.ctypes.data_as(C.POINTER(C.c_float)),
                                               data.points_.shape[0]))
             return
-        rc = lib.bpf_shard_score_planar(e.h, data.ranges_.ctypes.data_as(C.POINTER(C.c_double)),
-                                        data.angles_.ctypes.data_as(C.POINTER(C.c_double)), data.range_count_,
-                                        data.range_max_)
+        rp, ap = data.pointers()
+        rc = lib.bpf_shard_score_planar(e.h, rp, ap, data.range_count_, data.range_max_)
         if rc != 100:  # BPF_SHARD_NEED_BEAM_COUNTS
             e.check(rc)
             return None
