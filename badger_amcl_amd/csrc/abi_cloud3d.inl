@@ -10,6 +10,13 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
                   nz = (long long)max_cells[2] - min_cells[2] + 1;
   if (w <= 0 || h <= 0 || nz <= 0 || (size_t)(w * h) != n_pose_indices)
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "pose_indices size does not match the cell bounds");
+  // the scoring kernel forms the column's byte offset with a 24-bit multiply-add and 32-bit offsets, and folds the
+  // lower cell bounds into a double addend (kernels_cloud.hpp)
+  if (w >= (1 << 22) || h >= (1 << 24) || n_pose_indices >= (1ull << 30))
+    return e->fail(BPF_ERR_CAPACITY, "3-D map wider than 2^22 cells, longer than 2^24 or with more than 2^30 columns");
+  for (int d = 0; d < 3; ++d)
+    if (std::abs((long long)min_cells[d]) >= (1 << 20) || std::abs((long long)max_cells[d]) >= (1 << 20))
+      return e->fail(BPF_ERR_CAPACITY, "3-D map cell bounds beyond +-2^20");
   // every column start must leave room for a whole z column (octomap.cpp:315-333)
   for (size_t i = 0; i < n_pose_indices; ++i)
     if ((size_t)pose_indices[i] + (size_t)nz > n_distance_ratios)

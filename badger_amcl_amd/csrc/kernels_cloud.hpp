@@ -39,7 +39,7 @@ struct CloudModelDev
   double tf_quat[4];  // x y z w
 };
 
-constexpr int kCloudChunk = 2048;  // points per LDS chunk (24 KB as float SoA -> 6 blocks per CU)
+constexpr int kCloudChunk = 2048;  // points per LDS chunk (24 KB as float SoA -> 6 blocks per CU); a multiple of 256
 
 // point_cloud_scanner.cpp:231-248 restated: q = q_yaw * q_scanner (double), t = R_yaw*t_s + (x,y,0),
 // narrowed to float, Eigen's quaternion->matrix formula in float.
@@ -110,6 +110,28 @@ __device__ __forceinline__ int voxel_of(float v, double res, double rinv)
   return (f == f) ? (int)f : 0x7fffffff;
 }
 
+// The scoring kernel's forms: inputs are finite by construction (non-finite points and poses are replaced at staging
+// by 1e30, which ends off the map exactly as the reference's (int)floor(NaN) = INT_MIN does), so the NaN test is
+// gone, and the lower bound of the map is folded in.  Exact-reciprocal form: v * rinv has <= 29 significant bits
+// and |0.5 - min| < 2^21, so fma(v, rinv, 0.5 - min) is exact (or, for |v| < 2^-22, stays strictly between the
+// same two integers) and its floor is the reference's cell minus min.  v_cvt_i32_f64 saturates for huge values.
+__device__ __forceinline__ int voxel_rel_exact(float v, double rinv, double half_minus_min)
+{
+  return (int)floor(fma((double)v, rinv, half_minus_min));
+}
+
+__device__ __forceinline__ int voxel_rel(float v, double res, double rinv, int min_c)
+{
+#pragma clang fp contract(off)
+  const double d = (double)v;
+  double q = d * rinv;
+  const double rem = fma(-q, res, d);
+  q = fma(rem, rinv, q);
+  return (int)floor(q + 0.5) - min_c;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct CloudScoreArgs
 {
   int n;
@@ -134,30 +156,42 @@ __device__ unsigned long long g_cloud_span[8192][2];  // diagnostic builds: per-
 #endif
 
 template <bool EXACT_RINV>
-__global__ __launch_bounds__(256) void k_cloud_score(const CloudScoreArgs A)
+__global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
 {
 #pragma clang fp contract(off)
 #ifdef BPF_PHASE_TIMING
   const long long _w0 = wall_clock64();
 #endif
   __shared__ float s_pts[3][kCloudChunk];
-  __shared__ double s_table[257];
+  // [0, 256): the term per distance ratio; [256]: the off-map term; [257]: zero (padding lanes of the last group).
+  // An evaluation's byte offset is max(ratio << 3, bad) with bad = 0 (on the map), 2048 or 2056.
+  __shared__ double s_table[258];
   const int chunk = blockIdx.x;
   const int p0 = chunk * kCloudChunk;
   const int np = min(kCloudChunk, A.n_points - p0);
-  for (int i = threadIdx.x; i < np; i += 256)
+  const int np_pad = (np + 255) & ~255;  // whole groups of 256 points; the padding is finite and contributes zero
+  for (int i = threadIdx.x; i < np_pad; i += 256)
   {
-    s_pts[0][i] = A.points[p0 + i];
-    s_pts[1][i] = A.points[(size_t)A.n_points + p0 + i];
-    s_pts[2][i] = A.points[2 * (size_t)A.n_points + p0 + i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+      const float v = (i < np) ? A.points[(size_t)k * A.n_points + p0 + i] : 0.f;
+      s_pts[k][i] = (fabsf(v) <= 3.0e38f) ? v : 1.0e30f;  // NaN / inf: a finite coordinate that is off every map
+    }
   }
-  for (int i = threadIdx.x; i < 257; i += 256)
-    s_table[i] = A.table[i];
+  for (int i = threadIdx.x; i < 258; i += 256)
+    s_table[i] = (i < 257) ? A.table[i] : 0.0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const Map3dDev& M = A.map;
-  const int span_x = M.max_c[0] - M.min_c[0], span_y = M.max_c[1] - M.min_c[1], span_z = M.max_c[2] - M.min_c[2];
+  const unsigned span_x = (unsigned)(M.max_c[0] - M.min_c[0]), span_y = (unsigned)(M.max_c[1] - M.min_c[1]),
+                 span_z = (unsigned)(M.max_c[2] - M.min_c[2]);
+  const double hm0 = 0.5 - (double)M.min_c[0], hm1 = 0.5 - (double)M.min_c[1], hm2 = 0.5 - (double)M.min_c[2];
+  const unsigned width4 = (unsigned)M.width * 4u;
+  const char* table_b = reinterpret_cast<const char*>(s_table);
+  const char* pose_b = reinterpret_cast<const char*>(M.pose_indices);
+  const int n_groups = np_pad >> 8;  // wave-uniform: every lane walks the same groups
 
   int j_begin = blockIdx.y * 4 + wave, j_end = A.n, j_step = A.slabs * 4;
   if (A.round_count[0] > 0)
@@ -175,50 +209,91 @@ __global__ __launch_bounds__(256) void k_cloud_score(const CloudScoreArgs A)
     const int j = __builtin_amdgcn_readfirstlane(jv);
     const float* a = A.affine + (size_t)j * 12;
     float R[12];
+    bool finite = true;
 #pragma unroll
     for (int k = 0; k < 12; ++k)
+    {
       R[k] = a[k];
-    double acc = 0.0;
-    // one evaluation up to the column: byte index into distance_ratios of the voxel, or -1 off the map
-    auto locate = [&](int q, unsigned& col, unsigned& ck_out) -> bool {
-      const float px = s_pts[0][q], py = s_pts[1][q], pz = s_pts[2][q];
-      const float wx = ((R[0] * px + R[1] * py) + R[2] * pz) + R[9];
-      const float wy = ((R[3] * px + R[4] * py) + R[5] * pz) + R[10];
-      const float wz = ((R[6] * px + R[7] * py) + R[8] * pz) + R[11];
-      const int ci = (EXACT_RINV ? voxel_of_exact(wx, M.inv_resolution) : voxel_of(wx, M.resolution, M.inv_resolution)) - M.min_c[0];
-      const int cj = (EXACT_RINV ? voxel_of_exact(wy, M.inv_resolution) : voxel_of(wy, M.resolution, M.inv_resolution)) - M.min_c[1];
-      const int ck = (EXACT_RINV ? voxel_of_exact(wz, M.inv_resolution) : voxel_of(wz, M.resolution, M.inv_resolution)) - M.min_c[2];
-      const bool ok = (unsigned)ci <= (unsigned)span_x && (unsigned)cj <= (unsigned)span_y && (unsigned)ck <= (unsigned)span_z;
-      col = ok ? (unsigned)cj * (unsigned)M.width + (unsigned)ci : 0u;
-      ck_out = ok ? (unsigned)ck : 0u;
-      return ok;
-    };
-    constexpr int U = 4;  // independent two-level gathers in flight per lane
-    int q = lane;
-    for (; q + 64 * (U - 1) < np; q += 64 * U)
-    {
-      unsigned col[U], ck[U], start[U], lvl[U];
-      bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        ok[u] = locate(q + 64 * u, col[u], ck[u]);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        start[u] = M.pose_indices[col[u]];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        lvl[u] = M.distance_ratios[(size_t)start[u] + ck[u]];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        acc += s_table[ok[u] ? lvl[u] : 256u];
+      finite = finite && (fabsf(R[k]) <= 3.0e38f);
     }
-    for (; q < np; q += 64)
+    if (!finite)
     {
-      unsigned col, ck;
-      const bool ok = locate(q, col, ck);
-      const unsigned start = M.pose_indices[col];
-      const unsigned lvl = M.distance_ratios[(size_t)start + ck];
-      acc += s_table[ok ? lvl : 256u];
+      // a NaN / inf pose puts every point off the map in the reference; same here through finite numbers
+#pragma unroll
+      for (int k = 0; k < 12; ++k)
+        R[k] = 0.f;
+      R[9] = 1.0e30f;
+    }
+    double acc = 0.0;
+    // Cell of one transformed point relative to the map's lower corner -> byte offset of its column's entry in
+    // pose_indices (24-bit multiply-add; bounds checked in bpf_map3d_set), level index, and `bad` (0 on the map,
+    // 2048 = the table's off-map entry otherwise).  Off-map points still gather, from the clamped cell: selects on the addresses turn into
+    // exec-mask branches, five scalar instructions per evaluation in a kernel that is bound by its instruction
+    // count (measured: SQ_ACTIVE_INST_ANY x 4 cycles / SIMD = the kernel's duration).
+    auto cell = [&](float wx, float wy, float wz, unsigned& col, unsigned& ck) -> unsigned {
+      const unsigned ci = (unsigned)(EXACT_RINV ? voxel_rel_exact(wx, M.inv_resolution, hm0)
+                                                : voxel_rel(wx, M.resolution, M.inv_resolution, M.min_c[0]));
+      const unsigned cj = (unsigned)(EXACT_RINV ? voxel_rel_exact(wy, M.inv_resolution, hm1)
+                                                : voxel_rel(wy, M.resolution, M.inv_resolution, M.min_c[1]));
+      const unsigned cz = (unsigned)(EXACT_RINV ? voxel_rel_exact(wz, M.inv_resolution, hm2)
+                                                : voxel_rel(wz, M.resolution, M.inv_resolution, M.min_c[2]));
+      const bool ok = ci <= span_x && cj <= span_y && cz <= span_z;
+      col = __umul24(min(cj, span_y), width4) + (min(ci, span_x) << 2);
+      ck = min(cz, span_z);
+      return ok ? 0u : 2048u;
+    };
+    // Two points at a time: the float transform R*p + t with separately rounded products and sums (no contraction),
+    // as packed f32 operations -- lane halves = the two points (q and q + 64 sit 64 floats apart in LDS, which is
+    // what ds_read2st64 fetches as a register pair).
+    const f32x2 r0 = { R[0], R[0] }, r1 = { R[1], R[1] }, r2 = { R[2], R[2] }, r3 = { R[3], R[3] },
+                r4 = { R[4], R[4] }, r5 = { R[5], R[5] }, r6 = { R[6], R[6] }, r7 = { R[7], R[7] },
+                r8 = { R[8], R[8] }, t0 = { R[9], R[9] }, t1 = { R[10], R[10] }, t2 = { R[11], R[11] };
+    constexpr int U = 4;  // points per lane and group: independent two-level gathers in flight (two pairs)
+    // cells of the U points of group g and the first-level gathers for them
+    auto stage1 = [&](int g, unsigned (&start)[U], unsigned (&ck)[U], unsigned (&bad)[U]) {
+      const int q0 = (g << 8) + lane;
+      unsigned col[U];
+#pragma unroll
+      for (int h = 0; h < U / 2; ++h)
+      {
+        const int qa = q0 + 128 * h, qb = qa + 64;
+        const f32x2 px = { s_pts[0][qa], s_pts[0][qb] }, py = { s_pts[1][qa], s_pts[1][qb] },
+                    pz = { s_pts[2][qa], s_pts[2][qb] };
+        const f32x2 wx = ((r0 * px + r1 * py) + r2 * pz) + t0;
+        const f32x2 wy = ((r3 * px + r4 * py) + r5 * pz) + t1;
+        const f32x2 wz = ((r6 * px + r7 * py) + r8 * pz) + t2;
+        bad[2 * h] = cell(wx.x, wy.x, wz.x, col[2 * h], ck[2 * h]);
+        bad[2 * h + 1] = cell(wx.y, wy.y, wz.y, col[2 * h + 1], ck[2 * h + 1]);
+      }
+      if (g == n_groups - 1 && np != np_pad)
+      {
+        // the padding lanes of the chunk's last group evaluate a harmless point and add the table's zero
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          bad[u] = (q0 + 64 * u < np) ? bad[u] : 2056u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        start[u] = *reinterpret_cast<const uint32_t*>(pose_b + col[u]);
+    };
+    // Software pipeline over the groups: while the second-level gathers of group g are in flight, the cells and
+    // first-level gathers of group g + 1 are formed and issued.
+    unsigned start_c[U], ck_c[U], bad_c[U];
+    stage1(0, start_c, ck_c, bad_c);
+    for (int g = 0; g < n_groups; ++g)
+    {
+      unsigned lvl[U], bad_now[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        lvl[u] = M.distance_ratios[start_c[u] + ck_c[u]];
+        bad_now[u] = bad_c[u];
+      }
+      if (g + 1 < n_groups)
+        stage1(g + 1, start_c, ck_c, bad_c);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        acc += *reinterpret_cast<const double*>(table_b + max(lvl[u] << 3, bad_now[u]));
     }
     const double tot = wave_sum(acc);
     if (lane == 0)
