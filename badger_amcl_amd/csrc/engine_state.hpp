@@ -177,6 +177,7 @@ struct bpf_engine
   bool window_lds_attr_set = false;
   bool beam_lds_attr_set = false;
   bool graded_shares = true;    // BPF_OPT_GRADED_SHARES
+  DevBuf<int> d_beam_counter;   // work counter of k_score_beam
   bool window_enabled = false;  // measured: no gain on wide clouds; opt-in via BPF_OPT_WINDOW_PATH
   bool last_used_window_path = false;
   DevBuf<unsigned long long> d_cells_walked;

@@ -436,6 +436,10 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     }
     if ((int)beams.size() > kMaxBeams)
       return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
+    // the ray walk forms cell offsets with 24-bit multiply-adds and 32-bit offsets (calc_range_skip)
+    if (!(range_max / e->map.resolution < 2097152.0) ||
+        (long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 31) || e->map.size_x + 3 >= (1 << 23))
+      return e->fail(BPF_ERR_CAPACITY, "beam model: range_max beyond 2^21 cells, or a map of 2^31 cells or more");
     // Rays of similar length walk together: order the beams by observed range so that the 64 lanes
     // of one iteration finish their Bresenham walks at about the same step (the per-particle sum is
     // order-independent up to rounding).  NaN ranges sort last.
@@ -467,6 +471,7 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     A.range_max = range_max;
     A.z_hit = pm.z_hit;
     A.denom = 2 * pm.sigma_hit * pm.sigma_hit;
+    A.inv_resolution = 1.0 / e->map.resolution;
     A.cells_walked = nullptr;
     if (e->count_cells)
     {
@@ -482,16 +487,15 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
                                                      bytes) != hipSuccess || api_blocks < 1)
       api_blocks = 1;
     const int per_cu = std::max(1, std::min(api_blocks, 6));
-    // rays differ in length, so cut the set ~4x finer than one range per resident wave
-    A.per_wave = std::max(1, blocks_for(n, e->n_cu * per_cu * 4 * 4));
-    const int grid = std::max(1, blocks_for(blocks_for(n, A.per_wave), 4));
-    A.block_partials = nullptr;
-    if (want_partials)
-    {
-      HIPCHK(e, e->d_block_partials.reserve((size_t)grid));
-      A.block_partials = e->d_block_partials.p;
-      e->fused_partials = grid;
-    }
+    // one resident round of blocks; the waves fetch their particles from a counter (k_score_beam), a few at a time
+    // so that the round drains evenly: ~16 grabs per wave, at most 16 particles each
+    A.per_wave = std::max(1, std::min(16, blocks_for(n, e->n_cu * per_cu * 4 * 16)));
+    const int grid = std::max(1, std::min(e->n_cu * per_cu, blocks_for(blocks_for(n, A.per_wave), 4)));
+    HIPCHK(e, e->d_beam_counter.reserve(1));
+    HIPCHK(e, hipMemsetAsync(e->d_beam_counter.p, 0, sizeof(int), e->stream));
+    A.next_particle = e->d_beam_counter.p;
+    A.block_partials = nullptr;  // dynamic assignment: the total comes from the fixed-shape sum over the weights
+    (void)want_partials;
     LAUNCH_TIMED(e, BPF_K_SCORE, k_score_beam, dim3(grid), dim3(256), bytes, A);
     HIPCHK(e, hipGetLastError());
     e->evals_last = (long long)n * (long long)beams.size();

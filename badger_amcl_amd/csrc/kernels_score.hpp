@@ -45,6 +45,18 @@ __device__ __forceinline__ int world_to_cell(double v, double origin, double res
   return (f == f) ? (int)f + half : -1;
 }
 
+// The same with the division as a corrected reciprocal multiply (q = d*r; q += fma(-q, res, d)*r): the correctly
+// rounded quotient but for vanishingly rare double roundings, at a fifth of the instructions of an IEEE division.
+// Used where the conversion runs once per ray (beam model).
+__device__ __forceinline__ int world_to_cell_rcp(double v, double origin, double res, double rinv, int half)
+{
+  const double d = v - origin;
+  double q = d * rinv;
+  q = fma(fma(-q, res, d), rinv, q);
+  const double f = floor(q + 0.5);
+  return (f == f) ? (int)f + half : -1;
+}
+
 constexpr int kLutPad = 1;  // border cells (holding the off-map level) on each side of the LUT image
 
 // Clamp a padded cell coordinate into [0, size + 1]: negative values wrap to huge unsigned numbers
@@ -478,26 +490,40 @@ __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y
   const int sx = (x0 < x1) ? 1 : -1, sy = (y0 < y1) ? 1 : -1;
   const int maj_dx = steep ? 0 : sx, maj_dy = steep ? sy : 0;
   const int min_dx = steep ? sx : 0, min_dy = steep ? 0 : sy;
-  const double inv2d = 1.0 / (2.0 * (double)dmaj);
+  // 1 / (2 dmaj) to a few ulp (hardware estimate + two Newton steps): the quotient below only has to land within
+  // 1e-6 of the true one
+  const double two_d = 2.0 * (double)dmaj;
+  double inv2d = __builtin_amdgcn_rcp(two_d);
+  inv2d = fma(fma(-two_d, inv2d, 1.0), inv2d, inv2d);
+  inv2d = fma(fma(-two_d, inv2d, 1.0), inv2d, inv2d);
   const int last = dmaj + 1;  // the reference tests cells j = 0 .. dmaj + 1
   const int stride = M.size_x + 2;
-  int j = 0;
+  // The walk itself is kept to a dozen instructions per visited cell (the kernel is bound by its instruction
+  // count): the cell after j major and m minor steps sits at base + j * step_major + m * step_minor in the padded
+  // chessboard-distance grid, all three formed once per ray; 24-bit multiply-adds (|step| <= size_x + 3 < 2^23,
+  // j, m <= range_max / resolution + 1, checked where the map is set).
+  const int step_major = maj_dy * stride + maj_dx, step_minor = min_dy * stride + min_dx;
+  const int base = (y0 + 1) * stride + (x0 + 1);
+  const int two_dmin = 2 * dmin;
+  const unsigned char* cheb = M.cheb;
+  int j = 0, m = 0;
+  bool hit;
   for (;;)
   {
     // minor-axis advance after j steps; the 1e-6 absorbs the reciprocal's rounding (fractional parts
     // of the true quotient are multiples of 1/(2*dmaj) >= 1e-4)
-    const int m = (int)fma((double)(2 * j * dmin + dmaj), inv2d, 1e-6);
-    const int x = x0 + maj_dx * j + min_dx * m, y = y0 + maj_dy * j + min_dy * m;
-    const int d = M.cheb[(y + 1) * stride + (x + 1)];
-    if (d == 0)
-    {
-      walked += (unsigned long long)(j + 1);
-      const int ddx = x - x0, ddy = y - y0;
-      return sqrt((double)(ddx * ddx + ddy * ddy)) * M.resolution;
-    }
-    if (j >= last)
+    m = (int)fma((double)(__mul24(j, two_dmin) + dmaj), inv2d, 1e-6);
+    const int d = cheb[(unsigned)(__mul24(j, step_major) + __mul24(m, step_minor) + base)];
+    hit = d == 0;
+    if (hit || j >= last)  // (this shape compiles to one block of 22 instructions; testing d after the loop does not)
       break;
     j = min(j + d, last);
+  }
+  if (hit)
+  {
+    walked += (unsigned long long)(j + 1);
+    const int ddx = maj_dx * j + min_dx * m, ddy = maj_dy * j + min_dy * m;
+    return sqrt((double)(ddx * ddx + ddy * ddy)) * M.resolution;
   }
   walked += (unsigned long long)(last + 1);
   return range_max;
@@ -513,8 +539,10 @@ struct BeamModelArgs
   double sp_x, sp_y, sp_th;
   double off_map_factor, non_free_factor, non_free_radius;
   double range_max, z_hit, denom;
+  double inv_resolution;  // correctly rounded 1 / resolution
   unsigned long long* cells_walked;
-  int per_wave;
+  int per_wave;          // particles per grab (<= 16)
+  int* next_particle;    // work counter, zero at launch
   double* block_partials;
 };
 
@@ -536,10 +564,19 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
   unsigned long long walked = 0;
   double wsum = 0.0;
 
-  const int wid = blockIdx.x * 4 + wave;
-  const int p_begin = min(A.n, wid * A.per_wave), p_end = min(A.n, p_begin + A.per_wave);
-  for (int base = p_begin; base < p_end; base += 16)
+  // Rays differ in length and so do the particles' costs: the waves of the one resident round take their particles
+  // from a counter, A.per_wave at a time, until it runs past n (every wave reaches that exit).  Which wave scores
+  // which particle therefore varies from run to run -- the weights do not, and the weight total is formed afterwards
+  // by the fixed-shape sum over the weights, not from per-block partials.
+  for (;;)
   {
+    int base = 0;
+    if (lane == 0)
+      base = atomicAdd(A.next_particle, A.per_wave);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= A.n)
+      break;
+    const int p_end = min(A.n, base + A.per_wave);
     const int cnt = min(16, p_end - base);
     const int pi = base + min(sub, cnt - 1);
     const double px = A.p.x[pi], py = A.p.y[pi], pth = A.p.th[pi];
@@ -559,8 +596,8 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
         const BeamRec B = s_beams[b];
         const double ca = c * B.cb - s * B.sb;  // cos(theta + bearing)
         const double sa = s * B.cb + c * B.sb;
-        const int x1 = world_to_cell(ox + A.range_max * ca, M.origin_x, M.resolution, M.half_x);
-        const int y1 = world_to_cell(oy + A.range_max * sa, M.origin_y, M.resolution, M.half_y);
+        const int x1 = world_to_cell_rcp(ox + A.range_max * ca, M.origin_x, M.resolution, A.inv_resolution, M.half_x);
+        const int y1 = world_to_cell_rcp(oy + A.range_max * sa, M.origin_y, M.resolution, A.inv_resolution, M.half_y);
         const double map_range = calc_range_skip(M, sx0, sy0, x1, y1, A.range_max, walked);
         const double z = B.obs - map_range;
         double pz = 0.0;

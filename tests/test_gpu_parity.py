@@ -42,6 +42,21 @@ def test_apply_model_to_sample_set_matches_oracle(engine, orc, model, cloud):
     assert abs(total - want_total) <= 1e-9 * abs(want_total)
 
 
+@pytest.mark.parametrize("cloud,n", [("converged", 5000), ("mixture", 1000), ("converged", 63)])
+def test_beam_model_longer_scan_and_more_particles(engine, orc, cloud, n):
+    """The beam model on a 181-beam scan decimated to 91 rays, sets large enough to give every wave several trips."""
+    sc_ = Scenario(orc, size=200, n=n, beams=181, cloud=cloud, frac_nan=0.0)  # the beam model does not skip NaN ranges
+    want = sc_.samples.copy()
+    want_total = sc_.oracle_apply(sc_.oracle_planar(91, "beam"), want)
+    assert want_total == want_total
+    m, sc, pf, data = sc_.gpu_objects(engine, 91, "beam")
+    w = sc_.samples.copy()
+    total = sc.applyModelToSampleSet(data, w, 0)
+    bad = rel_err(w[:, 3], want[:, 3]) > W_TOL
+    assert bad.sum() <= _knife_edge_budget(n * 91), np.flatnonzero(bad)[:10]
+    assert abs(total - want_total) <= 1e-9 * abs(want_total)
+
+
 def test_lf_decimation_and_single_particle(engine, orc):
     """max_beams < range_count (step > 1), N = 1, zero scanner offset."""
     sc_ = Scenario(orc, size=200, n=1, beams=181, cloud="converged", scanner_pose=(0.0, 0.0, 0.0))
