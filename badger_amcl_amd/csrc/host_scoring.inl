@@ -440,15 +440,8 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     if (!(range_max / e->map.resolution < 2097152.0) ||
         (long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 31) || e->map.size_x + 3 >= (1 << 23))
       return e->fail(BPF_ERR_CAPACITY, "beam model: range_max beyond 2^21 cells, or a map of 2^31 cells or more");
-    // Rays of similar length walk together: order the beams by observed range so that the 64 lanes
-    // of one iteration finish their Bresenham walks at about the same step (the per-particle sum is
-    // order-independent up to rounding).  NaN ranges sort last.
-    std::stable_sort(beams.begin(), beams.end(), [](const BeamRec& a, const BeamRec& b) {
-      const bool an = a.obs != a.obs, bn = b.obs != b.obs;
-      if (an || bn)
-        return !an && bn;
-      return a.obs > b.obs;
-    });
+    // The beams stay in bearing order: one trip of a wave then casts 64 neighbouring bearings from one pose, which
+    // pass much the same cells (measured: 2.73 ms against 2.98 ms with the beams ordered by observed range).
     const size_t bytes = beams.size() * sizeof(BeamRec);
     ScanSlot* s;
     int rcode = acquire_slot(e, bytes, &s);
@@ -488,7 +481,8 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
       api_blocks = 1;
     const int per_cu = std::max(1, std::min(api_blocks, 6));
     // one resident round of blocks; the waves fetch their particles from a counter (k_score_beam), a few at a time
-    // so that the round drains evenly: ~16 grabs per wave, at most 16 particles each
+    // so that the round drains evenly: ~16 grabs per wave, at most 16 particles each (100 k particles: 2 per grab;
+    // 1, 2 and 4 measure alike, 8 costs 8 %, 16 costs 23 %)
     A.per_wave = std::max(1, std::min(16, blocks_for(n, e->n_cu * per_cu * 4 * 16)));
     const int grid = std::max(1, std::min(e->n_cu * per_cu, blocks_for(blocks_for(n, A.per_wave), 4)));
     HIPCHK(e, e->d_beam_counter.reserve(1));

@@ -546,8 +546,8 @@ struct BeamModelArgs
   double* block_partials;
 };
 
-// Beam model: calcBeamModel (planar_scanner.cpp:168-234).  Wave = particle, lanes = beams (sorted by
-// observed range on the host so that the lanes of one iteration cast rays of similar length).
+// Beam model: calcBeamModel (planar_scanner.cpp:168-234).  Wave = particle, lanes = beams in bearing order (the 64
+// rays of one trip are neighbouring bearings from one pose and pass much the same cells).
 __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
 {
   extern __shared__ __align__(16) unsigned char smem[];
