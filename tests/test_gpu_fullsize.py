@@ -269,3 +269,51 @@ def test_graded_shares_3d(engine, orc):
     orc.cloud_apply(op, olut, want, pts)
     rel = np.abs(out[1][0][idx] - want[:, 3]) / want[:, 3]
     assert (rel > 1e-9).sum() <= 1  # one point within rounding of a voxel face may resolve differently
+
+
+def test_one_million_particles_on_one_gpu(engine, world, orc):
+    """BASELINE config 4's particle count (1 M) on a single GPU: the CDF takes its two-launch form (more than 256
+    tiles of 2 048 weights), the scoring kernel's ranges are ten times longer.  Size-independent checks: a particle's
+    weight does not depend on how the set is cut (the same million scored in ten host-buffer calls of 100 k), the
+    normalised weights sum to one, and the resample equals the oracle's on the weights the GPU produced (exact:
+    count, leaf count, RNG state, poses)."""
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    n = 1000000
+    samples = synth.converged_cloud(n, world["pose"], seed=77)
+    samples[:, 3] = np.random.default_rng(5).uniform(0.5, 1.5, n) / n
+    sc, data = world["sc"], world["data"]
+    pf = bpf.ParticleFilter(engine, 100, n, 0.0, 0.0, 85.0)
+    pf.srand48(9)
+    pf.initWithSamples(samples)
+    engine.set_option(hpf.OPT_CDF_SERIAL, 0)
+    assert sc.updateSensor(pf, data)
+    st0 = pf.getState()
+    before = pf.getCurrentSet().samples
+    assert abs(before[:, 3].sum() - 1.0) < 1e-11
+    # the same particles in ten separate calls (un-normalised weights): equal up to the normalisation
+    raw = np.empty(n)
+    for k in range(10):
+        part = np.ascontiguousarray(samples[k * 100000:(k + 1) * 100000])
+        sc.applyModelToSampleSet(data, part, 0)
+        raw[k * 100000:(k + 1) * 100000] = part[:, 3]
+    assert np.allclose(raw / raw.sum(), before[:, 3], rtol=1e-12, atol=0)
+    assert np.array_equal(raw / st0.total, before[:, 3]) or rel_max(raw / st0.total, before[:, 3]) < 1e-15
+    pf.updateResample()
+    st1 = pf.getState()
+    after = pf.getCurrentSet().samples
+    opf = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0, seed=9)
+    opf.set_samples(before, leaf_count=st0.leaf_count)
+    out = opf.update_resample()
+    assert out.status == 0
+    # the parallel CDF differs from the oracle's serial one by rounding: a draw within that distance of a CDF step may
+    # pick the neighbouring particle (none expected in ~3 000 draws; allow one and require everything else exact)
+    assert st1.sample_count == out.sample_count and st1.leaf_count == out.leaf_count
+    assert pf.getRngState() == opf.pf.rng
+    diff = np.flatnonzero(np.any(after[:, :3] != opf.samples[:out.sample_count, :3], axis=1))
+    assert diff.size <= 1, diff[:5]
+    assert np.all(after[:, 3] == 1.0 / out.sample_count)
+
+
+def rel_max(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
