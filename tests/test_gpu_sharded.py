@@ -427,3 +427,58 @@ def test_mailbox_exchange_with_ranks_out_of_step(tmp_path):
         merged = np.concatenate([r0["samples"], r1["samples"]])
         assert np.array_equal(merged[:, :3], pf.getCurrentSet().samples[:, :3]), cycle
     e.close()
+
+
+def _silent_peer(handle_path, stop_path):
+    """Creates a mailbox as rank 1 of 2, publishes its handle and then never takes part in an exchange."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import time
+    import badger_amcl_amd as bpf
+    e = bpf.Engine(0)
+    buf = (C.c_ubyte * 64)()
+    e.check(e.lib.bpf_shard_mailbox_create(e.h, 1, 2, 1024, buf))
+    with open(handle_path + ".tmp", "wb") as f:
+        f.write(bytes(buf))
+    os.rename(handle_path + ".tmp", handle_path)
+    for _ in range(200):  # keep the allocation alive until the test is done (at most 20 s)
+        if os.path.exists(stop_path):
+            break
+        time.sleep(0.1)
+    e.close()
+
+
+def test_mailbox_connect_gives_up_when_a_peer_never_answers(tmp_path):
+    """The waits of the mailbox exchange are bounded: a rank whose peer maps nothing and posts nothing gets
+    BPF_ERR_EXCHANGE from the connect round after 5 s instead of a kernel that spins for ever."""
+    import ctypes as C
+    import time
+    import torch.multiprocessing as mp
+    import badger_amcl_amd as bpf
+    handle_path, stop_path = str(tmp_path / "handle"), str(tmp_path / "stop")
+    ctx = mp.get_context("spawn")
+    peer = ctx.Process(target=_silent_peer, args=(handle_path, stop_path))
+    peer.start()
+    try:
+        for _ in range(300):
+            if os.path.exists(handle_path):
+                break
+            time.sleep(0.1)
+        assert os.path.exists(handle_path)
+        theirs = open(handle_path, "rb").read()
+        e = bpf.Engine(0)
+        mine = (C.c_ubyte * 64)()
+        e.check(e.lib.bpf_shard_mailbox_create(e.h, 0, 2, 1024, mine))
+        t0 = time.time()
+        rc = e.lib.bpf_shard_mailbox_connect(e.h, C.c_char_p(bytes(mine) + theirs))
+        waited = time.time() - t0
+        assert rc == 9, (rc, e.lib.bpf_last_error_message(e.h))  # BPF_ERR_EXCHANGE
+        assert 4.0 < waited < 9.0, waited
+        # the engine is still usable and the mailbox can be dropped
+        assert e.lib.bpf_shard_mailbox_destroy(e.h) == 0
+        e.close()
+    finally:
+        open(stop_path, "w").close()
+        peer.join(30)
+        if peer.is_alive():
+            peer.kill()
