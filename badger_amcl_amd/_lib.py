@@ -41,6 +41,7 @@ SIGNATURES = {
                                 C.c_float, C.c_double, C.c_double]),
     "bpf_map2d_build_distances_lut": (C.c_int, [_vp, C.c_double]),
     "bpf_map2d_get_distances_lut": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t]),
+    "bpf_map2d_calc_range": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     "bpf_planar_init": (C.c_int, [_vp, C.c_int]),
     "bpf_planar_set_model_beam": (C.c_int, [_vp] + [C.c_double] * 6),
     "bpf_planar_set_model_likelihood_field": (C.c_int, [_vp] + [C.c_double] * 4),

@@ -82,6 +82,34 @@ int bpf_map2d_build_distances_lut(bpf_engine* e, double max_dist)
   return build_lut_device(e, max_dist);
 }
 
+int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, const double* cos_a, const double* sin_a,
+                         const double* max_range, int n, double* range_out)
+{
+  if (!e || !ox || !oy || !cos_a || !sin_a || !max_range || !range_out || n <= 0)
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "calc_range: null argument or n <= 0") : BPF_ERR_INVALID_ARGUMENT;
+  if (!e->have_map)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
+  // the walk forms cell offsets with 24-bit multiply-adds and 32-bit offsets (calc_range_skip)
+  if ((long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 31) || e->map.size_x + 3 >= (1 << 23))
+    return e->fail(BPF_ERR_CAPACITY, "calc_range: a map of 2^31 cells or more");
+  for (int i = 0; i < n; ++i)
+    if (!(std::fabs(max_range[i]) / e->map.resolution < 2097152.0))
+      return e->fail(BPF_ERR_CAPACITY, "calc_range: max_range beyond 2^21 cells (or not finite)");
+  HIPCHK(e, hipSetDevice(e->device));
+  DevBuf<double> in, out;
+  HIPCHK(e, in.reserve((size_t)5 * n));
+  HIPCHK(e, out.reserve((size_t)n));
+  const double* src[5] = { ox, oy, cos_a, sin_a, max_range };
+  for (int k = 0; k < 5; ++k)
+    HIPCHK(e, hipMemcpyAsync(in.p + (size_t)k * n, src[k], (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_calc_range, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->map, in.p, in.p + n,
+                     in.p + 2 * (size_t)n, in.p + 3 * (size_t)n, in.p + 4 * (size_t)n, n, out.p);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(range_out, out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return BPF_OK;
+}
+
 int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity)
 {
   if (!e || !out)

@@ -643,4 +643,22 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
   }
 }
 
+// OccupancyMap::calcRange (occupancy_map.cpp:257-364) for a batch of rays: origin (ox, oy), direction given as
+// (cos, sin) of the ray's angle -- formed by the caller, as the reference forms them with libm -- and max range.
+__global__ void k_calc_range(const MapDev M, const double* __restrict__ ox, const double* __restrict__ oy,
+                             const double* __restrict__ ca, const double* __restrict__ sa,
+                             const double* __restrict__ max_range, int n, double* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const double mr = max_range[i];
+  const int x0 = world_to_cell(ox[i], M.origin_x, M.resolution, M.half_x);
+  const int y0 = world_to_cell(oy[i], M.origin_y, M.resolution, M.half_y);
+  const int x1 = world_to_cell(ox[i] + mr * ca[i], M.origin_x, M.resolution, M.half_x);
+  const int y1 = world_to_cell(oy[i] + mr * sa[i], M.origin_y, M.resolution, M.half_y);
+  unsigned long long walked = 0;
+  out[i] = calc_range_skip(M, x0, y0, x1, y1, mr, walked);
+}
+
 }  // namespace bpf

@@ -13,6 +13,7 @@ own call sequence:
 All computation happens in libbadger_pf_hip.so on the GPU.  This module only marshals.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -168,6 +169,18 @@ class OccupancyMap:
         self.e.check(self.e.lib.bpf_map2d_build_distances_lut_reference(self.e.h, float(max_distance_to_object)))
         self.max_distance_to_object = float(max_distance_to_object)
         self.lut = None
+
+    def calcRange(self, ox, oy, oa, max_range):
+        """OccupancyMap::calcRange (occupancy_map.cpp:257-364), batched: arrays of origins, angles and max ranges."""
+        ox, oy, oa = (np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (ox, oy, oa))
+        mr = np.ascontiguousarray(np.broadcast_to(np.asarray(max_range, dtype=np.float64), ox.shape))
+        # libm's cos / sin (what the reference calls), not numpy's vector loops, which may differ in the last bit
+        ca = np.array([math.cos(a) for a in oa], dtype=np.float64)
+        sa = np.array([math.sin(a) for a in oa], dtype=np.float64)
+        out = np.zeros(ox.shape[0], dtype=np.float64)
+        self.e.check(self.e.lib.bpf_map2d_calc_range(self.e.h, _dp(ox), _dp(oy), _dp(ca), _dp(sa), _dp(mr),
+                                                     ox.shape[0], _dp(out)))
+        return out
 
     def getDistancesLUT(self):
         out = np.zeros((self.size_y, self.size_x), dtype=np.float32)

@@ -91,6 +91,13 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
  * host LUT to bpf_map2d_set when parity with it matters. */
 int bpf_map2d_build_distances_lut(bpf_engine* e, double max_dist);
 int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity);
+/* OccupancyMap::calcRange(ox, oy, oa, max_range) (occupancy_map.cpp:257-364) for n rays: the integer Bresenham
+ * walk from the cell of (ox, oy) towards the cell of the max-range end point, distance to the first cell that is off
+ * the map or not FREE (max_range if none; 0 for a start off the map).  The direction comes as cos(oa), sin(oa),
+ * formed by the caller as the reference forms them (libm), so that the end cell is the reference's bit for bit.
+ * Needs only the cells (bpf_map2d_set); host buffers in and out. */
+int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, const double* cos_a, const double* sin_a,
+                         const double* max_range, int n, double* range_out);
 /* OccupancyMap::updateDistancesLUT exactly as the reference builds it (occupancy_map.cpp:138-252):
  * priority-queue brushfire on the host (std::priority_queue, so tie order matches a libstdc++
  * build of the reference), ~2 s for a 2000 x 2000 map.  Parity mode for SURVEY 8(f) next-3. */

@@ -103,6 +103,17 @@ def test_gpu_hits_beamskip(engine):
 
 
 @pytest.mark.gpu
+def test_gpu_hits_calc_range(engine):
+    """The device's jumping walk (chessboard-distance grid) against the cell-by-cell walk of the oracle on the ray
+    fan: all octants and their borders, starts on and off the map, zero and long max ranges.  Exact."""
+    import badger_amcl_amd as bpf
+    g = _load("calc_range")
+    m = _map2d(bpf, engine, g, with_lut=False)
+    got = m.calcRange(g["ox"], g["oy"], g["oa"], g["max_range"])
+    assert np.array_equal(got, g["ranges"]), np.flatnonzero(got != g["ranges"])[:10]
+
+
+@pytest.mark.gpu
 def test_gpu_hits_lut_reference(engine):
     import badger_amcl_amd as bpf
     g = _load("lut_reference")

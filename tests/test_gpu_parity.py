@@ -368,6 +368,24 @@ def test_prob_beamskip_matches_oracle(engine, orc):
     assert np.array_equal(got[:, 3], want[:, 3])
 
 
+def test_calc_range_matches_the_cell_by_cell_walk(engine, orc):
+    """OccupancyMap::calcRange through the C-ABI (jumping walk over the chessboard-distance grid) against the
+    oracle's cell-by-cell Bresenham on 20 000 random rays: exact, including rays that run the whole 30 m."""
+    import math
+    sc_ = Scenario(orc, size=400, n=4, beams=11)
+    m, sc, pf, data = sc_.gpu_objects(engine, 11, "beam")
+    rng = np.random.default_rng(12)
+    n = 20000
+    ext = 400 * 0.05
+    ox, oy = rng.uniform(-0.5, ext + 0.5, n), rng.uniform(-0.5, ext + 0.5, n)
+    oa = rng.uniform(-math.pi, math.pi, n)
+    mr = rng.choice([0.3, 2.0, 8.0, 30.0], n)
+    got = m.calcRange(ox, oy, oa, mr)
+    want = np.array([sc_.omap.calc_range(float(a), float(b), float(c), float(d)) for a, b, c, d in zip(ox, oy, oa, mr)])
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert (want < mr).mean() > 0.3 and (want == mr).mean() > 0.05
+
+
 def test_beam_model_step_zero_is_refused(engine, orc):
     import badger_amcl_amd as bpf
     sc_ = Scenario(orc, size=200, n=10, beams=20)
