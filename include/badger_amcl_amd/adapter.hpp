@@ -14,6 +14,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cmath>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -106,6 +107,15 @@ public:
     lut_.clear();
   }
   double getMaxDistanceToObject() const { return max_dist_; }
+  // OccupancyMap::calcRange (occupancy_map.cpp:257-364); cos / sin from libm here, as the reference forms them
+  double calcRange(double ox, double oy, double oa, double max_range)
+  {
+    upload();
+    const double ca = std::cos(oa), sa = std::sin(oa);
+    double out = 0.0;
+    e_->check(bpf_map2d_calc_range(e_->get(), &ox, &oy, &ca, &sa, &max_range, 1, &out));
+    return out;
+  }
   void upload()
   {
     if (!dirty_)
