@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the sharded filter logic (no GPU): two ranks, each holding half of
+"""world_size-2 (and -3) gloo test of the sharded filter logic (no GPU): the ranks each hold a part of
 the particle set, must reproduce what one process computes on the whole set."""
 import os
 import socket
@@ -76,14 +76,17 @@ def _worker(rank, world, port, out_dir, cloud_split, resampler, recovery):
 
 @pytest.mark.parametrize("split,resampler,recovery", [((0, 600, 1200), 0, False), ((0, 137, 1200), 0, False),
                                                       ((0, 500, 1200), 1, False), ((0, 700, 1200), 0, True),
-                                                      ((0, 300, 1200), 1, True)])
-def test_two_shards_equal_one_filter(tmp_path, split, resampler, recovery):
-    """recovery: the node's default decay rates and a worsening scan, so that w_diff > 0 and both resamplers
+                                                      ((0, 300, 1200), 1, True), ((0, 100, 650, 1200), 0, False),
+                                                      ((0, 413, 800, 1200), 1, True)])
+def test_shards_equal_one_filter(tmp_path, split, resampler, recovery):
+    """Two or three ranks (the split says how many and how unevenly the initial set is cut).
+    recovery: the node's default decay rates and a worsening scan, so that w_diff > 0 and both resamplers
     mix in random free-space poses (every rank resolves the same draw chain, shard 0 writes the random poses)."""
     sys.path.insert(0, HERE)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), split, resampler, recovery), nprocs=2, join=True)
-    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(2)]
+    W = len(split) - 1
+    mp.spawn(_worker, args=(W, port, str(tmp_path), split, resampler, recovery), nprocs=W, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(W)]
 
     orc, sc = _scenario()
     n = sc.samples.shape[0]
@@ -103,23 +106,24 @@ def test_two_shards_equal_one_filter(tmp_path, split, resampler, recovery):
         out = opf.update_resample()
         w_diffs.append(out.w_diff)
         assert out.status == 0
-        r0, r1 = recs[0][cycle], recs[1][cycle]
+        rr = [recs[k][cycle] for k in range(W)]
         # normalised weights: rank-ordered total vs the serial total differ by rounding only
-        w_sh = np.concatenate([r0["w"][:, 3], r1["w"][:, 3]])
+        w_sh = np.concatenate([r["w"][:, 3] for r in rr])
         assert np.allclose(w_sh, w_ref, rtol=1e-12, atol=0)
-        for r in (r0, r1):
+        for r in rr:
             assert r["M"] == out.sample_count
             assert r["leaf"] == out.leaf_count and r["bins"] == out.node_count
             assert r["rng"] == opf.pf.rng
             assert r["conv"] == out.converged
             assert abs(r["w_slow"] - opf.pf.w_slow) <= 1e-12 * opf.pf.w_slow + 0.0
         M = out.sample_count
-        merged = np.concatenate([r0["samples"], r1["samples"]])
+        merged = np.concatenate([r["samples"] for r in rr])
         assert merged.shape[0] == M
         assert np.array_equal(merged[:, :3], opf.samples[:M, :3])
         assert np.all(merged[:, 3] == 1.0 / M)
         # shards are the even, index-ordered split
-        assert r0["samples"].shape[0] == M // 2 and r1["samples"].shape[0] == M - M // 2
+        for k in range(W):
+            assert rr[k]["samples"].shape[0] == (M * (k + 1)) // W - (M * k) // W
     if recovery:
         assert max(w_diffs) > 0.01  # the recovery branch really ran
     if resampler == 0:
