@@ -482,3 +482,38 @@ def test_mailbox_connect_gives_up_when_a_peer_never_answers(tmp_path):
         peer.join(30)
         if peer.is_alive():
             peer.kill()
+
+
+def test_three_ranks_mailbox_equal_single_engine(tmp_path):
+    """Three processes on cuda:0 exchanging through the mailbox (an odd world size: uneven shards, three slots per
+    exchange), two motion -> sensor -> resample cycles, against one engine on the whole set."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    W = 3
+    mp.spawn(_worker, args=(W, port, str(tmp_path), "converged", 8192, 0, "mailbox"), nprocs=W, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r), allow_pickle=True) for r in range(W)]
+    import badger_amcl_amd as bpf
+    orc, sc = _scenario("converged")
+    n = sc.samples.shape[0]
+    e = bpf.Engine(0)
+    m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    od = bpf.Odom(e)
+    od.setModel(*ODOM)
+    for cycle in range(2):
+        od.updateAction(pf, bpf.OdomData(*ODATA))
+        scn.updateSensor(pf, data)
+        w_ref = pf.getCurrentSet().samples[:, 3].copy()
+        pf.updateResample()
+        st = pf.getState()
+        rr = [recs[k][cycle] for k in range(W)]
+        assert np.allclose(np.concatenate([r["w"][:, 3] for r in rr]), w_ref, rtol=1e-12, atol=0)
+        for r in rr:
+            assert r["M"] == st.sample_count and r["leaf"] == st.leaf_count and r["bins"] == st.bin_count
+            assert r["rng"] == pf.getRngState() and not r["miss"]
+        merged = np.concatenate([r["samples"] for r in rr])
+        assert np.array_equal(merged[:, :3], pf.getCurrentSet().samples[:, :3])
+        M = st.sample_count
+        for k in range(W):
+            assert rr[k]["samples"].shape[0] == (M * (k + 1)) // W - (M * k) // W
+    e.close()
