@@ -366,6 +366,21 @@ def main():
             dth = (time.perf_counter() - t0h) / 10
             host_path = {"ms_per_update": dth * 1e3, "evals_per_s": float(wl["n"]) * wl["beams"] / dth,
                          "what": "applyModelToSampleSet with host buffers: 3.2 MB H2D + scoring + 3.2 MB D2H per call"}
+            # the whole cycle with the set crossing PCIe both ways (SURVEY 8(d)'s end-to-end figure): H2D of the set
+            # (32 B/particle), sensor update, resample, D2H of the resampled set -- never `value` either
+            pf.initWithSamples(wl["samples"])
+            sc.updateSensor(pf, data)
+            pf.updateResample()
+            pf.getCurrentSet()
+            t0h = time.perf_counter()
+            for _ in range(10):
+                pf.initWithSamples(wl["samples"])
+                sc.updateSensor(pf, data)
+                pf.updateResample()
+                pf.getCurrentSet()
+            dte = (time.perf_counter() - t0h) / 10
+            host_path["end_to_end_cycle_ms"] = dte * 1e3
+            host_path["end_to_end_evals_per_s"] = float(wl["n"]) * wl["beams"] / dte
         score = prof["score"]
         k_ms = score["ms"] / max(score["launches"], 1)
         if args.model == "beam":
