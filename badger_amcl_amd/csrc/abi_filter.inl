@@ -90,6 +90,11 @@ int bpf_pf_get_rng_state(const bpf_engine* e, uint64_t* state48)
   return BPF_OK;
 }
 
+namespace
+{
+int finish_init(bpf_engine* e, int n);  // abi_motion.inl
+}
+
 int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, int leaf_count)
 {
   if (!e || !samples)
@@ -117,15 +122,12 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
   }
   else
   {
-    e->hist.clear();
-    for (int i = 0; i < sample_count; ++i)
-    {
-      int key[3];
-      host_pose_key(samples[4 * i], samples[4 * i + 1], samples[4 * i + 2], key);
-      e->hist.insert(key[0], key[1], key[2]);
-    }
-    e->leaf_count = e->hist.leaf_count();
-    e->bin_count = e->hist.bin_count();
+    // the set's histogram tree, as the reference builds it when a set is created: on the device for large sets
+    // (0.5 ms instead of ~2 ms of host insertion for 100 k samples), host otherwise -- the same as after
+    // initWithGaussian / initWithPoseFn
+    rc = finish_init(e, sample_count);
+    if (rc != BPF_OK)
+      return rc;
   }
   HIPCHK(e, hipStreamSynchronize(e->stream));  // h_aos staging is reused by the next call
   return BPF_OK;
