@@ -112,6 +112,7 @@ SIGNATURES = {
     "bpf_shard_converged_dev": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "bpf_shard_mailbox_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_longlong, _vp]),
     "bpf_shard_mailbox_connect": (C.c_int, [_vp, _vp]),
+    "bpf_shard_mailbox_selftest": (C.c_int, [_vp, C.c_int]),
     "bpf_shard_mailbox_destroy": (C.c_int, [_vp]),
     "bpf_shard_mailbox_totals": (C.c_int, [_vp, C.POINTER(_vp)]),
     "bpf_shard_mailbox_window": (C.c_int, [_vp, C.POINTER(_vp), _ip]),

@@ -127,6 +127,35 @@ int bpf_shard_mailbox_connect(bpf_engine* e, const void* handles)
   return rc;
 }
 
+int bpf_shard_mailbox_selftest(bpf_engine* e, int rounds)
+{
+  if (!e || rounds < 1 || rounds > 64)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (!e->mb.active)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "mailbox not connected");
+  if (e->mb.win_wait)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "mailbox: an exchange is in flight");
+  HIPCHK(e, hipSetDevice(e->device));
+  const int n_cols = (int)std::min<long long>(e->mb.max_window, 4096);
+  const int blocks = blocks_for(n_cols, 256);  // <= 16 blocks: the check may wait with all of them
+  for (int r = 0; r < rounds; ++r)
+  {
+    const unsigned long long g = ++e->mb.win_gen;
+    e->h_mb_result.p[0] = 0;
+    hipLaunchKernelGGL(k_mailbox_selftest_write, dim3(blocks), dim3(256), 0, e->stream, mailbox_dev(e), n_cols,
+                       (int)(g & 1), g, e->d_mb_counter.p);
+    hipLaunchKernelGGL(k_mailbox_selftest_check, dim3(blocks), dim3(256), 0, e->stream, mailbox_dev(e), n_cols,
+                       (int)(g & 1), g, e->h_mb_result.p);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (int rc = mailbox_check(e))
+      return rc;
+    if (e->h_mb_result.p[0] != 0)
+      return e->fail(BPF_ERR_EXCHANGE, "mailbox self-test: window cells did not arrive as their owners wrote them");
+  }
+  return BPF_OK;
+}
+
 int bpf_shard_mailbox_destroy(bpf_engine* e)
 {
   if (!e)

@@ -128,6 +128,46 @@ __global__ void k_mailbox_wait(const MailboxDev M, int which, int parity, unsign
   mb_block_wait(M, which == 0 ? mb_tot_gen(M.peer[M.rank], parity, 0) : mb_win_done(M.peer[M.rank], parity, 0), gen);
 }
 
+// Self-test of the window path with a payload that can be checked: rank r stores pattern(r, gen, column) into the
+// columns c = r (mod world) of every peer's window, posts "done"; the check kernel waits for all ranks and counts the
+// cells that do not hold what their owner must have written.
+__device__ __forceinline__ long long mb_pattern(int rank, unsigned long long gen, int row, int col)
+{
+  return (long long)(((unsigned long long)(rank + 1) << 48) ^ (gen << 32) ^ ((unsigned long long)row << 24) ^
+                     (unsigned long long)col * 0x9E3779B1ull);
+}
+
+__global__ void k_mailbox_selftest_write(const MailboxDev M, int n_cols, int parity, unsigned long long gen,
+                                         unsigned* counter)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_cols && c % M.world == M.rank)
+    for (int r = 0; r < M.world; ++r)
+    {
+      long long* win = mb_window(M.peer[r], parity, M.max_window);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        win[(size_t)k * (size_t)M.max_window + c] = mb_pattern(M.rank, gen, k, c);
+    }
+  mb_window_done_when_last(M, parity, gen, counter);
+}
+
+__global__ void k_mailbox_selftest_check(const MailboxDev M, int n_cols, int parity, unsigned long long gen,
+                                         int* mismatches)
+{
+  mb_block_wait(M, mb_win_done(M.peer[M.rank], parity, 0), gen);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols)
+    return;
+  const long long* win = mb_window(M.peer[M.rank], parity, M.max_window);
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    bad += win[(size_t)k * (size_t)M.max_window + c] != mb_pattern(c % M.world, gen, k, c);
+  if (bad)
+    atomicAdd(mismatches, bad);
+}
+
 // connect-time self-test: one full round (post to every peer, wait for every peer); result[0] = 1 when all arrived
 __global__ void k_mailbox_hello(const MailboxDev M, unsigned long long token, int* result)
 {

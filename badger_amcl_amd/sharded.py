@@ -64,6 +64,10 @@ class HipShardBackend:
         """Maps the peers (handles: world x 64 bytes in rank order) and runs one round with all of them."""
         return self.e.lib.bpf_shard_mailbox_connect(self.e.h, C.c_char_p(handles)) == 0
 
+    def mailbox_selftest(self, rounds=4):
+        """Full window exchanges with a payload every rank verifies (both parities, twice)."""
+        return self.e.lib.bpf_shard_mailbox_selftest(self.e.h, rounds) == 0
+
     def mailbox_destroy(self):
         self.e.lib.bpf_shard_mailbox_destroy(self.e.h)
 
@@ -294,6 +298,9 @@ class ShardedFilter:
         ok = self._all_agree(handle is not None)
         if ok:
             ok = self._all_agree(b.mailbox_connect(handles))
+        if ok:
+            # the words arrive; do the window cells?  (a peer's stores must be visible behind this GPU's caches)
+            ok = self._all_agree(b.mailbox_selftest())
         if not ok:
             b.mailbox_destroy()
         return ok

@@ -416,6 +416,10 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
 #define BPF_MAILBOX_HANDLE_BYTES 64
 int bpf_shard_mailbox_create(bpf_engine* e, int rank, int world, long long max_window, void* handle_out);
 int bpf_shard_mailbox_connect(bpf_engine* e, const void* handles);
+/* `rounds` full window exchanges with a checkable payload (every rank writes a pattern into its share of the columns
+ * of every peer, every rank verifies all columns after the wait); all ranks must call it together, after connect.
+ * BPF_ERR_EXCHANGE when a cell did not arrive as written or a wait ran out. */
+int bpf_shard_mailbox_selftest(bpf_engine* e, int rounds);
 int bpf_shard_mailbox_destroy(bpf_engine* e);
 int bpf_shard_mailbox_totals(bpf_engine* e, void** totals_dev);
 int bpf_shard_mailbox_window(bpf_engine* e, void** window_dev, int* stride);
