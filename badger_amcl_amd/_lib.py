@@ -113,6 +113,8 @@ SIGNATURES = {
     "bpf_shard_mailbox_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_longlong, _vp]),
     "bpf_shard_mailbox_connect": (C.c_int, [_vp, _vp]),
     "bpf_shard_mailbox_selftest": (C.c_int, [_vp, C.c_int]),
+    "bpf_shard_mailbox_update_sensor_planar": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_longlong]),
+    "bpf_shard_mailbox_update_resample": (C.c_int, [_vp, _vp, _ip, _ip, _ip, _ip, _ip]),
     "bpf_shard_mailbox_destroy": (C.c_int, [_vp]),
     "bpf_shard_mailbox_totals": (C.c_int, [_vp, C.POINTER(_vp)]),
     "bpf_shard_mailbox_window": (C.c_int, [_vp, C.POINTER(_vp), _ip]),

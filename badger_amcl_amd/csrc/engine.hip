@@ -54,5 +54,6 @@ void mailbox_release(bpf_engine* e);  // abi_mailbox.inl
 #include "abi_cloud3d.inl"
 #include "abi_mailbox.inl"
 #include "abi_sharded.inl"
+#include "abi_mailbox_step.inl"
 #include "abi_measure.inl"
 }  // extern "C"

@@ -275,6 +275,9 @@ struct bpf_engine
     unsigned long long hello = 0;
     int fold_deferred = 0;          // > 0: that many scoring partials wait to be folded and posted by the normalise launch
   } mb;
+  void* mb_totals = nullptr;        // bpf_shard_mailbox_update_sensor_planar: this update's totals (mailbox slots)
+  bool mb_totals_valid = false;
+  DevBuf<double> d_shard_out;       // [3][max_samples] poses of a resample that spans several windows
   PinnedBuf<unsigned> h_mb_error;
   PinnedBuf<int> h_mb_result;
   DevBuf<unsigned> d_mb_counter;

@@ -48,6 +48,7 @@ class HipShardBackend:
         engine.check(engine.lib.bpf_shard_scalars_dev(engine.h, C.byref(p)))
         self.scalars = torch.as_tensor(_DevArray(p.value, (16,), "<f8"), device=device)
         self._total_view, self._sum_view = self.scalars[0:1], self.scalars[7:8]
+        self._engine_device_min = None
 
     def n_local(self):
         return self.pf.getState().sample_count
@@ -63,6 +64,29 @@ class HipShardBackend:
     def mailbox_connect(self, handles):
         """Maps the peers (handles: world x 64 bytes in rank order) and runs one round with all of them."""
         return self.e.lib.bpf_shard_mailbox_connect(self.e.h, C.c_char_p(handles)) == 0
+
+    def mailbox_update_sensor(self, data, global_n):
+        """Scoring, exchange of the totals and normalisation in one call; None when beam skipping needs the
+        caller's all-reduce in between (the stage functions finish the update then)."""
+        rp, ap = data.pointers()
+        rc = self.e.lib.bpf_shard_mailbox_update_sensor_planar(self.e.h, rp, ap, data.range_count_, data.range_max_,
+                                                               int(global_n))
+        if rc == 100:  # BPF_SHARD_NEED_BEAM_COUNTS
+            return None
+        self.e.check(rc)
+        return True
+
+    def mailbox_update_resample(self, flags, global_n, leaf_count, window_hint):
+        """updateResample of the shard in one call: (M, leaf_count, bin_count, windows, window_hint)."""
+        if self._engine_device_min != self.kld_device_min:
+            self.e.set_option(3, int(self.kld_device_min) if self.kld_device_min < (1 << 31) else 0)  # KLD_DEVICE_MIN
+            self._engine_device_min = self.kld_device_min
+        g, lf, bn, wn, hint = (C.c_int(int(global_n)), C.c_int(int(leaf_count)), C.c_int(0), C.c_int(0),
+                               C.c_int(int(window_hint)))
+        self.e.check(self.e.lib.bpf_shard_mailbox_update_resample(self.e.h, C.c_void_p(flags.data_ptr()), C.byref(g),
+                                                                  C.byref(lf), C.byref(bn), C.byref(wn),
+                                                                  C.byref(hint)))
+        return g.value, lf.value, bn.value, wn.value, hint.value
 
     def mailbox_selftest(self, rounds=4):
         """Full window exchanges with a payload every rank verifies (both parities, twice)."""
@@ -103,6 +127,11 @@ class HipShardBackend:
         # beam skipping: the per-beam agreement counts have to be summed over the shards first
         p, n = C.c_void_p(), C.c_int()
         e.check(lib.bpf_shard_beam_counts_dev(e.h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DevArray(p.value, (n.value,), "<i4"), device=self.device)
+
+    def beam_counts(self):
+        p, n = C.c_void_p(), C.c_int()
+        self.e.check(self.e.lib.bpf_shard_beam_counts_dev(self.e.h, C.byref(p), C.byref(n)))
         return torch.as_tensor(_DevArray(p.value, (n.value,), "<i4"), device=self.device)
 
     def score_finish(self, data, global_n):
@@ -266,6 +295,7 @@ class ShardedFilter:
         self.leaf_count = self.bin_count = 0
         self.windows_used = 0
         self.totals = None  # per-shard weight totals of the last update_sensor (None: weights changed since)
+        self._fused_totals = False  # the last update_sensor went through the engine's one-call mailbox form
         # exchange: "mailbox" = peer stores through IPC-mapped device memory (all ranks on one node), "collective" =
         # torch.distributed all-gather / all-reduce, "auto" = mailbox when every rank could set it up
         self.mailbox = False
@@ -360,6 +390,21 @@ class ShardedFilter:
 
     # ---- Seam A
     def update_sensor(self, data):
+        if self.mailbox and not hasattr(data, "points_") and hasattr(self.b, "mailbox_update_sensor"):
+            # mailbox: the exchange is inside the kernels, so the whole update is one call into the engine
+            if self.b.mailbox_update_sensor(data, self.sample_count):
+                self.totals = self.b.mailbox_totals()
+                self._fused_totals = True
+                return
+            # beam skipping: the counting pass has run; sum its counts over the shards and finish stage by stage
+            counts = self.b.beam_counts()
+            self._all_reduce_sum(counts)
+            self.b.score_finish(data, self.sample_count)
+            self.totals = self.b.mailbox_totals()
+            self.b.normalize(self.totals, self.sample_count)
+            self._fused_totals = False
+            return
+        self._fused_totals = False
         counts = self.b.score(data)
         if counts is not None:
             # prob model with beam skipping: one extra all-reduce of max_beams int32 between its two passes
@@ -421,6 +466,17 @@ class ShardedFilter:
     # ---- Seam B (multinomial, w_diff == 0)
     def update_resample(self):
         b, W = self.b, self.world
+        if self.mailbox and getattr(self, "_fused_totals", False) and hasattr(b, "mailbox_update_resample"):
+            # one call: CDF, windows, stop rule, adoption of this rank's share (bpf_shard_mailbox_update_resample)
+            leaf_in = self._global_leaf_count() if b.resample_model() == 1 else self.leaf_count
+            M, leaf, bins, wins, hint = b.mailbox_update_resample(self.flags, self.sample_count, leaf_in,
+                                                                  self.window_hint)
+            self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
+            self.sample_count, self.leaf_count, self.bin_count = M, leaf, bins
+            self.windows_used, self.window_hint = wins, hint
+            self.totals = None
+            self._fused_totals = False
+            return
         if b.resample_model() == 1:  # PF_RESAMPLE_SYSTEMATIC
             return self._update_resample_systematic()
         b.build_cdf(self.flags)
@@ -497,6 +553,7 @@ class ShardedFilter:
         self.counts = list(counts)
         self.sample_count = sum(counts)
         self.totals = None
+        self._fused_totals = False
         self.leaf_count = leaf_count
 
     def state(self):

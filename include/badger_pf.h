@@ -416,6 +416,18 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
 #define BPF_MAILBOX_HANDLE_BYTES 64
 int bpf_shard_mailbox_create(bpf_engine* e, int rank, int world, long long max_window, void* handle_out);
 int bpf_shard_mailbox_connect(bpf_engine* e, const void* handles);
+/* Mailbox mode, the sharded sensor update and resample as one call each: what badger_amcl_amd/sharded.py does with
+ * the stage functions above, in the same order, with the exchanges inside the kernels -- so that a host pays one
+ * call per update.  update_sensor: bpf_shard_score_planar + totals + bpf_shard_normalize_dev (returns
+ * BPF_SHARD_NEED_BEAM_COUNTS unchanged when beam skipping needs the caller's all-reduce: finish with the stage
+ * functions then).  update_resample: multinomial (windows sized from *window_hint_io, follow-up windows, whole-stream
+ * device tree) or systematic; *global_count_io / *leaf_count_io: the global sample count and the leaf count of the
+ * current set's tree in, those of the new set out; this rank adopts its even share [M r / W, M (r + 1) / W);
+ * flags_dev as in bpf_shard_build_cdf / bpf_shard_draw_window_dev (int32[>= 1] on the device, [0] = CDF-miss flag). */
+int bpf_shard_mailbox_update_sensor_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                                           double range_max, long long global_count);
+int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* global_count_io, int* leaf_count_io,
+                                      int* bin_count_out, int* windows_out, int* window_hint_io);
 /* `rounds` full window exchanges with a checkable payload (every rank writes a pattern into its share of the columns
  * of every peer, every rank verifies all columns after the wait); all ranks must call it together, after connect.
  * BPF_ERR_EXCHANGE when a cell did not arrive as written or a wait ran out. */
