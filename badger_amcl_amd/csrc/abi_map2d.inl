@@ -93,8 +93,8 @@ int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, cons
   if ((long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 31) || e->map.size_x + 3 >= (1 << 23))
     return e->fail(BPF_ERR_CAPACITY, "calc_range: a map of 2^31 cells or more");
   for (int i = 0; i < n; ++i)
-    if (!(std::fabs(max_range[i]) / e->map.resolution < 2097152.0))
-      return e->fail(BPF_ERR_CAPACITY, "calc_range: max_range beyond 2^21 cells (or not finite)");
+    if (!(std::fabs(max_range[i]) / e->map.resolution < kMaxRayCells))
+      return e->fail(BPF_ERR_CAPACITY, "calc_range: max_range beyond 32 760 cells (or not finite)");
   HIPCHK(e, hipSetDevice(e->device));
   DevBuf<double> in, out;
   HIPCHK(e, in.reserve((size_t)5 * n));

@@ -6,6 +6,9 @@ namespace
 
 constexpr int kRing = 4;            // in-flight scan uploads
 constexpr int kMaxBeams = 4096;     // beams staged in LDS per launch
+// calc_range_skip forms j * 2 * dmin with a 24-bit multiply whose 32-bit result must not wrap: j <= c + 2,
+// dmin <= c + 1 for a ray of c = range_max / resolution cells -> 2 (c + 2)(c + 1) < 2^31 <=> c <= 32 765
+constexpr double kMaxRayCells = 32760.0;
 constexpr int kTableLdsMax = 2048;  // table entries that still go to LDS
 constexpr int kEventPool = 8192;
 

@@ -436,10 +436,11 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     }
     if ((int)beams.size() > kMaxBeams)
       return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
-    // the ray walk forms cell offsets with 24-bit multiply-adds and 32-bit offsets (calc_range_skip)
-    if (!(range_max / e->map.resolution < 2097152.0) ||
+    // the ray walk forms cell offsets with 24-bit multiply-adds and 32-bit offsets (calc_range_skip); its error term
+    // j * 2 * dmin (j <= dmaj + 1, dmin <= dmaj <= range_max / resolution + 1) must stay below 2^31
+    if (!(range_max / e->map.resolution < kMaxRayCells) ||
         (long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 31) || e->map.size_x + 3 >= (1 << 23))
-      return e->fail(BPF_ERR_CAPACITY, "beam model: range_max beyond 2^21 cells, or a map of 2^31 cells or more");
+      return e->fail(BPF_ERR_CAPACITY, "beam model: range_max beyond 32 760 cells, or a map of 2^31 cells or more");
     // The beams stay in bearing order: one trip of a wave then casts 64 neighbouring bearings from one pose, which
     // pass much the same cells (measured: 2.73 ms against 2.98 ms with the beams ordered by observed range).
     const size_t bytes = beams.size() * sizeof(BeamRec);

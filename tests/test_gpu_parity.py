@@ -339,10 +339,10 @@ def test_w_diff_positive_without_a_generator_is_refused_loudly(engine, orc):
     bad = bpf.PlanarData(np.full(61, 1.0), sc_.angles, sc_.range_max)
     sc.updateSensor(pf, bad)
     st = pf.getState()
-    if st.w_fast < st.w_slow:
-        with pytest.raises(bpf.BpfError) as ei:
-            pf.updateResample()
-        assert ei.value.code == 4
+    assert st.w_fast < st.w_slow  # the precondition of the branch under test, not a filter on it
+    with pytest.raises(bpf.BpfError) as ei:
+        pf.updateResample()
+    assert ei.value.code == 4
 
 
 def test_prob_beamskip_matches_oracle(engine, orc):

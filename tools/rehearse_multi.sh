@@ -7,7 +7,7 @@ STEPS=${2:-100}
 shift; shift
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 for X in auto collective; do
-  BPF_BENCH_REHEARSAL=1 BPF_SHARD_EXCHANGE=$X timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 \
-    --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 200)) \
-    bench.py --gpus $N --steps $STEPS --warmup 5 --cpu-budget 0 "$@" || exit 1
+  # no external launcher: bench.py --gpus N starts its own ranks when WORLD_SIZE is unset
+  BPF_BENCH_REHEARSAL=1 BPF_SHARD_EXCHANGE=$X timeout -k 10 300 python3 bench.py --gpus $N --steps $STEPS --warmup 5 \
+    --cpu-budget 0 "$@" || exit 1
 done
