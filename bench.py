@@ -171,19 +171,36 @@ def cpu_baseline(args, wl, lut, budget_s):
 
 def cpu_baseline_all_cores(args, wl, lut):
     """SURVEY.md section 8(d)'s generous figure: the same oracle with the scoring loop sharded over every host
-    core of a one-GPU job's share (at most 16; contiguous particle ranges, one thread each; ctypes releases the GIL), then the
-    serial normalisation and resampler.  One whole step."""
+    core of a one-GPU job's share (at most 16; contiguous particle ranges, one thread each; ctypes releases the GIL),
+    then the serial normalisation and resampler.  One whole step (of a quarter of the set for the beam model, of a
+    budgeted slice for the 3-D model)."""
     import threading
     from badger_amcl_amd import synth
     from oracle import pyoracle as orc
-    if args.model not in ("lf", "gompertz"):
-        return None
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 16))  # a one-GPU job's share of the host (the box runs one job per GPU)
-    omap = orc.OccupancyMap(wl["cells"], 0.05, wl["origin"], 2.0, lut)
-    kw = synth.LF_DEFAULTS if args.model == "lf" else synth.GOMPERTZ_LAUNCH
-    mid = orc.MODEL_LF if args.model == "lf" else orc.MODEL_LF_GOMPERTZ
     n = wl["n"]
+    if args.model == "cloud3d":
+        pi, dr, mn, mx = wl["lut3"]
+        olut = orc.OctoMapLUT(mn, mx, 0.05, 0.3, pi, dr)
+        n = min(n, max(100, int(args.cpu_budget * cores * 1.5e7 / wl["beams"])))
+
+        def score(view):
+            op = orc.cloud(orc.CLOUD_MODEL, wl["beams"], wl["tf_xyz"], wl["tf_quat"], z_hit=0.5, z_rand=0.05,
+                           sigma_hit=0.1)
+            op.off_map_factor = synth.MAP_FACTORS[0]
+            return orc.cloud_apply(op, olut, view, wl["points"])
+    else:
+        omap = orc.OccupancyMap(wl["cells"], 0.05, wl["origin"], 2.0, lut)
+        kw = {"lf": synth.LF_DEFAULTS, "gompertz": synth.GOMPERTZ_LAUNCH, "beam": synth.BEAM_DEFAULTS}[args.model]
+        mid = {"lf": orc.MODEL_LF, "gompertz": orc.MODEL_LF_GOMPERTZ, "beam": orc.MODEL_BEAM}[args.model]
+        if args.model == "beam":
+            n = max(1000, n // 4)
+
+        def score(view):
+            p = orc.planar(mid, wl["beams"], scanner_pose=synth.SCANNER_POSE, **kw)
+            p.off_map_factor, p.non_free_space_factor, p.non_free_space_radius = synth.MAP_FACTORS
+            return orc.planar_apply(p, omap, view, wl["ranges"], wl["angles"], 30.0, 0, None)
     opf = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0, seed=42)
     opf.set_resample_model(1 if args.resampler == "systematic" else 0)
     opf.set_samples(wl["samples"][:n], leaf_count=0)
@@ -191,9 +208,7 @@ def cpu_baseline_all_cores(args, wl, lut):
     totals = [0.0] * cores
 
     def work(t, view):
-        p = orc.planar(mid, wl["beams"], scanner_pose=synth.SCANNER_POSE, **kw)
-        p.off_map_factor, p.non_free_space_factor, p.non_free_space_radius = synth.MAP_FACTORS
-        totals[t] = orc.planar_apply(p, omap, view, wl["ranges"], wl["angles"], 30.0, 0, None)
+        totals[t] = score(view)
 
     def sensor(samples, conv):
         th = [threading.Thread(target=work, args=(t, samples[bounds[t]:bounds[t + 1]])) for t in range(cores)]
@@ -211,9 +226,9 @@ def cpu_baseline_all_cores(args, wl, lut):
     out = opf.update_resample()
     dt = time.perf_counter() - t0
     return dict(value=float(n) * wl["beams"] / dt, unit="particle-beam evals/s", cores=cores, kind="port",
-                sample="1 step of %d particles x %d beams, scoring on %d threads (contiguous particle ranges), serial "
-                       "normalise + resample, %.2f s; resampled to M=%d" % (n, wl["beams"], cores, dt,
-                                                                            out.sample_count))
+                sample="1 step of %d particles x %d beams (%s), scoring on %d threads (contiguous particle ranges), "
+                       "serial normalise + resample, %.2f s; resampled to M=%d" % (n, wl["beams"], args.model, cores, dt,
+                                                                                   out.sample_count))
 
 
 def apply_config_preset(args):
@@ -296,7 +311,7 @@ def metric_name(args):
         what, args.particles, beams, "points" if args.model == "cloud3d" else "beams")
 
 
-def pmc_evidence(model, cloud, k_ms):
+def pmc_evidence(model, cloud, k_ms, n, beams):
     """What the committed rocprofv3 PMC passes say binds the scoring kernel (profiles/pmc_traffic.json, written by
     tools/pmc_score.sh; static: not re-measured in this run, tagged with its source)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -305,8 +320,8 @@ def pmc_evidence(model, cloud, k_ms):
         rec = json.load(open(path)).get("%s_%s" % (model, cloud)) or json.load(open(path)).get(model)
     except Exception:
         rec = None
-    if not rec:
-        return out
+    if not rec or (rec.get("particles"), rec.get("beams")) != (n, beams):
+        return out  # counters of another workload say nothing about this one
     out["traffic"] = rec.get("hbm_bytes_per_launch")
     out["traffic_source"] = "static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % rec.get(
         "source", "profiles/pmc_traffic.json")
@@ -508,7 +523,7 @@ def main():
             e.set_option(1, 0)
         abytes = algorithmic_bytes(args.model, wl["n"], wl["beams"], mean_cells)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        ev = pmc_evidence(args.model, args.cloud, k_ms)
+        ev = pmc_evidence(args.model, args.cloud, k_ms, wl["n"], wl["beams"])
         backend_name = None if dist is None else dist.get_backend()
         line = {
             "metric": metric_name(args),
@@ -546,7 +561,7 @@ def main():
         for k in ("issue_frac", "hbm_measured_gbs"):
             if k in ev:
                 line["roofline"][k] = ev[k]
-        if mean_cells is not None:
+        if mean_cells is not None and args.model == "beam":
             line["roofline"]["mean_cells_per_ray"] = mean_cells
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
