@@ -394,7 +394,7 @@ int bpf_pf_update_sensor_cloud(bpf_engine* e, const float* points_xyz, int n_poi
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
   const int n = e->sample_count;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   int rc = score_cloud(e, s.dev(), n, points_xyz, n_points);
   if (rc != BPF_OK)
     return rc;

@@ -108,7 +108,7 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
   if (rc != BPF_OK)
     return rc;
   e->sample_count = sample_count;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->set_epoch++;
   e->hist_matches_set = leaf_count < 0;
   // initWith*: w_slow_ = w_fast_ = 0, converged = false (particle_filter.cpp:127,157,164-168)
@@ -186,7 +186,7 @@ int bpf_pf_restore(bpf_engine* e)
   e->sample_count = e->snap_count;
   e->leaf_count = e->snap_leaf;
   e->bin_count = e->snap_bins;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->set_epoch++;
   e->hist_matches_set = false;
   return BPF_OK;
@@ -196,7 +196,7 @@ int bpf_pf_fill_weights(bpf_engine* e, double weight)
 {
   if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->set_epoch++;
   HIPCHK(e, hipSetDevice(e->device));
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(e->sample_count, 256)), dim3(256), 0, e->stream,
@@ -233,12 +233,22 @@ int bpf_pf_update_sensor_planar(bpf_engine* e, const double* ranges, const doubl
     // running averages and leaves the tile sums for the CDF
     const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
     HIPCHK(e, e->d_tile_sums.reserve((size_t)nb));
-    ProfScope ps(e, BPF_K_NORMALIZE);
-    hipLaunchKernelGGL(k_normalize_fused, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
-                       e->d_block_partials.p, e->fused_partials, e->d_scalars.p, e->alpha_slow, e->alpha_fast,
-                       e->d_tile_sums.p);
-    HIPCHK(e, hipGetLastError());
-    e->tile_sums_n = n;
+    if (e->fused_resample && !e->cdf_serial && nb <= BPF_RED_BLOCK)
+    {
+      // ... and the resampling CDF in the same launch (kernels_fused.hpp): updateResample finds it ready
+      rc = launch_normalize_cdf(e, s.w.p, n);
+      if (rc != BPF_OK)
+        return rc;
+    }
+    else
+    {
+      ProfScope ps(e, BPF_K_NORMALIZE);
+      hipLaunchKernelGGL(k_normalize_fused, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
+                         e->d_block_partials.p, e->fused_partials, e->d_scalars.p, e->alpha_slow, e->alpha_fast,
+                         e->d_tile_sums.p);
+      HIPCHK(e, hipGetLastError());
+      e->tile_sums_n = n;
+    }
     e->fused_partials = 0;
   }
   else
@@ -301,11 +311,17 @@ int bpf_pf_update_resample(bpf_engine* e)
     HIPCHK(e, hipMemsetAsync(&e->d_scalars.p->v[1], 0, 2 * sizeof(double), e->stream));
   const int M = e->sample_count;
   SampleSet& b = e->sets[e->cur ^ 1];
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->cur ^= 1;
   e->leaf_count = e->kld_device_used ? e->kld_leaf : e->hist.leaf_count();
   e->bin_count = e->kld_device_used ? e->kld_bins : e->hist.bin_count();
-  if (M <= 8192)
+  if (e->fused_used)
+  {
+    // k_resample_block already wrote the weights and counted the converged particles
+    e->converged_pending = true;
+    e->conv_n = M;
+  }
+  else if (M <= 8192)
   {
     // small resampled set: weights 1/M and updateConverged in one single-block launch
     ProfScope ps(e, BPF_K_FINALIZE);
@@ -358,7 +374,7 @@ int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out)
   out->w_diff = e->w_diff_last;
   out->last_status = e->last_status;
   out->resample_windows = e->resample_windows;
-  out->kld_on_device = e->kld_device_used ? 1 : 0;
+  out->kld_on_device = e->fused_used ? 2 : (e->kld_device_used ? 1 : 0);
   out->reserved = 0;
   out->evals = e->evals_last;
   return BPF_OK;

@@ -144,7 +144,7 @@ int update_action(bpf_engine* e, const double pose[3], const double delta[3], co
     return rc;
   e->rng = lcg_skip_host(e->rng, (uint64_t)consumed, e->jump);
   e->cur ^= 1;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->fused_partials = 0;
   e->set_epoch++;
   e->hist_matches_set = false;
@@ -157,7 +157,7 @@ int finish_init(bpf_engine* e, int n)
 {
   SampleSet& s = e->sets[e->cur];
   e->sample_count = n;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->fused_partials = 0;
   e->set_epoch++;
   e->hist_matches_set = false;

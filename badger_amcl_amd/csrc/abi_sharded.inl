@@ -103,7 +103,7 @@ int bpf_shard_score_cloud(bpf_engine* e, const float* points_xyz, int n_points)
     return BPF_OK;
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   int rc = score_cloud(e, s.dev(), e->sample_count, points_xyz, n_points);
   if (rc != BPF_OK)
     return rc;
@@ -290,7 +290,7 @@ int bpf_shard_adopt_dev(bpf_engine* e, const void* x_dev, const void* y_dev, con
   e->sample_count = count;
   e->leaf_count = leaf_count;
   e->bin_count = bin_count;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   return BPF_OK;
 }
 
@@ -315,7 +315,7 @@ int bpf_shard_tail_small_dev(bpf_engine* e, const void* x_all_dev, const void* y
   e->sample_count = hi - lo;
   e->leaf_count = leaf_count;
   e->bin_count = bin_count;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->converged_pending = true;
   e->conv_n = global_count;
   return BPF_OK;
@@ -667,6 +667,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->kld_device_min = value > 0 ? value : 0x7fffffff;
   else if (option == BPF_OPT_GRADED_SHARES)
     e->graded_shares = value != 0;
+  else if (option == BPF_OPT_FUSED_RESAMPLE)
+    e->fused_resample = value != 0;
   else
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown option");
   return BPF_OK;

@@ -23,6 +23,7 @@
 #include "kernels_kld.hpp"
 #include "kernels_recovery.hpp"
 #include "kernels_pf.hpp"
+#include "kernels_fused.hpp"
 #include "kernels_score.hpp"
 #include "kernels_window.hpp"
 

@@ -231,6 +231,19 @@ struct bpf_engine
   DevBuf<double> d_cdf, d_partials, d_targets, d_block_partials, d_tile_sums;
   int fused_partials = 0;     // > 0: the last scoring launch left that many per-block weight partials
   int tile_sums_n = -1;       // >= 0: d_tile_sums holds the 2048-tile sums of the current weights for that n
+  int cdf_ready_n = -1;       // >= 0: d_cdf (and the guide) already hold the CDF of the current weights (k_normalize_cdf)
+  DevBuf<unsigned> d_tile_flags;
+  unsigned tile_generation = 0;
+  bool fused_resample = true; // BPF_OPT_FUSED_RESAMPLE
+  bool fused_lds_attr_set = false;
+  int fused_used = 0;         // the last resample ran as the one-block kernel
+  int fused_generation = 0;
+  PinnedBuf<int> h_fused;
+  DevBuf<FusedJump> d_fused_jump;
+  DevBuf<unsigned long long> d_fused_keys;
+  DevBuf<unsigned> d_fused_counter;
+  DevBuf<double> d_cdf_coarse;
+  int cdf_coarse_n = -1;      // d_cdf_coarse holds the subsample of the CDF in d_cdf for that n
   DevBuf<FilterScalars> d_scalars;
   DevBuf<int> d_keys, d_src_index, d_flags;  // d_flags[0] miss, [1] converged count
   DevBuf<double4> d_aos;

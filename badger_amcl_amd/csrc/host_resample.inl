@@ -18,14 +18,77 @@ int fetch_scalars(bpf_engine* e)
 
 // zero_word2 / sum_out (optional): a second miss flag to clear and where to leave c[n], both written by the scan
 // itself instead of by a memset and a copy behind it
-int build_cdf(bpf_engine* e, const double* w, int n, int* zero_word2 = nullptr, double* sum_out = nullptr)
+// k_resample_block stages every (1 << shift)-th CDF value in LDS: the smallest shift that fits kFusedCoarse brackets
+int fused_coarse_shift(int n)
 {
-  HIPCHK(e, e->d_cdf.reserve((size_t)n + 1));
+  int shift = 0;
+  while ((((n - 1) >> shift) + 1) > kFusedCoarse)
+    shift++;
+  return shift;
+}
+
+int ensure_cdf_buffers(bpf_engine* e, int n)
+{
+  HIPCHK(e, e->d_cdf.reserve((size_t)n + 1 + 64));  // slack: k_resample_block reads whole 32-value brackets
   if (!e->d_cdf_guide.p)
   {
     HIPCHK(e, e->d_cdf_guide.reserve(kCdfGuide + 2));
     HIPCHK(e, hipMemsetAsync(e->d_cdf_guide.p, 0xFF, (kCdfGuide + 2) * sizeof(int), e->stream));  // "no entry"
   }
+  return BPF_OK;
+}
+
+// ParticleFilter::updateSensor's normalisation and the CDF of the normalised weights in one launch (k_normalize_cdf);
+// needs the scoring kernel's per-block partials (e->fused_partials) and at most 256 tiles
+int launch_normalize_cdf(bpf_engine* e, double* w, int n)
+{
+  const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+  int rc = ensure_cdf_buffers(e, n);
+  if (rc != BPF_OK)
+    return rc;
+  if (e->d_tile_flags.cap < (size_t)BPF_RED_BLOCK)
+  {
+    HIPCHK(e, e->d_tile_flags.reserve((size_t)BPF_RED_BLOCK));
+    HIPCHK(e, hipMemsetAsync(e->d_tile_flags.p, 0, BPF_RED_BLOCK * sizeof(unsigned), e->stream));
+    e->tile_generation = 0;
+  }
+  NormCdfArgs A{};
+  A.w = w;
+  A.n = n;
+  A.block_partials = e->d_block_partials.p;
+  A.n_partials = e->fused_partials;
+  A.sc = e->d_scalars.p;
+  A.alpha_slow = e->alpha_slow;
+  A.alpha_fast = e->alpha_fast;
+  A.tile_sums = e->d_tile_sums.p;
+  A.tile_flags = e->d_tile_flags.p;
+  A.generation = ++e->tile_generation;
+  if (A.generation == 0)  // wrapped: 0 is the cleared state of the flags
+    A.generation = ++e->tile_generation;
+  A.cdf = e->d_cdf.p;
+  A.coarse_shift = fused_coarse_shift(n);
+  HIPCHK(e, e->d_cdf_coarse.reserve((size_t)kFusedCoarse + 2));
+  A.coarse = e->d_cdf_coarse.p;
+  A.guide = nullptr;  // k_resample_block searches through the subsample; the general path bisects without a head start
+  A.zero_word = e->d_flags.p;
+  ProfScope ps(e, BPF_K_NORMALIZE);
+  hipLaunchKernelGGL(k_normalize_cdf, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, A);
+  HIPCHK(e, hipGetLastError());
+  e->tile_sums_n = -1;
+  e->cdf_ready_n = n;
+  e->cdf_coarse_n = n;
+  e->cdf_guide_valid = false;
+  return BPF_OK;
+}
+
+int build_cdf(bpf_engine* e, const double* w, int n, int* zero_word2 = nullptr, double* sum_out = nullptr)
+{
+  if (e->cdf_ready_n == n && w == e->sets[e->cur].w.p && !e->cdf_serial && zero_word2 == nullptr && sum_out == nullptr)
+    return BPF_OK;  // k_normalize_cdf left it behind
+  int rcb = ensure_cdf_buffers(e, n);
+  if (rcb != BPF_OK)
+    return rcb;
+  e->cdf_coarse_n = -1;  // the scan kernels below leave no subsample
   e->cdf_guide_valid = !e->cdf_serial;
   ProfScope ps(e, BPF_K_CDF);
   if (e->cdf_serial)
@@ -44,7 +107,7 @@ int build_cdf(bpf_engine* e, const double* w, int n, int* zero_word2 = nullptr, 
     if (e->tile_sums_n == n && w == e->sets[e->cur].w.p)
     {
       tiles = e->d_tile_sums.p;  // left behind by k_normalize_fused; consumed (scanned in place) here
-      e->tile_sums_n = -1;
+      e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
     }
     else
     {
@@ -164,22 +227,14 @@ int build_draw_chain(bpf_engine* e, double w_diff, int max_draws)
   return BPF_OK;
 }
 
-// The KLD stop rule for the whole candidate stream [0, maxs) on the device (kernels_kld.hpp), keys in
-// e->d_keys (AoS): grows the histogram tree level by level and scans the leaf count.
-// Returns BPF_OK with *stop_out = stop count (or -1: no stop), *leaf_out / *bins_out at the final count;
-// *handled = false when a key does not fit the 64-bit packing or the tree is deeper than the level budget
-// (the caller then replays on the host as before).
-int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out,
-                       bool whole_stream = false)
+// resampleLimit per leaf count 0 .. upto on the device, cached per parameter set (host libm, as the reference
+// evaluates it)
+int ensure_limit_table(bpf_engine* e, int upto)
 {
-  *handled = false;
-  const int n = maxs;
-  if (n >= (1 << 30))
-    return BPF_OK;  // element indices 2v + side are folded as 32-bit tags
-  // resampleLimit per leaf count, cached per parameter set (host libm, as the reference evaluates it)
   if (e->kld_limit_key[0] != e->pop_err || e->kld_limit_key[1] != e->pop_z || e->kld_limit_key[2] != e->min_samples ||
-      e->kld_limit_key[3] != e->max_samples || (int)e->kld_limit_host.size() < n + 1)
+      e->kld_limit_key[3] != e->max_samples || (int)e->kld_limit_host.size() < upto + 1)
   {
+    const int n = std::max(upto, (int)e->kld_limit_host.size() - 1);
     e->kld_limit_host.resize((size_t)n + 1);
     for (int k = 0; k <= n; ++k)
       e->kld_limit_host[k] = resample_limit(k, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
@@ -192,6 +247,136 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
     e->kld_limit_key[2] = e->min_samples;
     e->kld_limit_key[3] = e->max_samples;
   }
+  return BPF_OK;
+}
+
+// The whole resample for a candidate stream of at most kFusedWindow draws as one single-block launch
+// (k_resample_block): draws, histogram tree and KLD stop, weights 1/M, updateConverged.  *handled = false when the
+// stop lies beyond the window, a key does not fit the packing or the tree is too deep: the caller runs the general path.
+int resample_block(bpf_engine* e, int window, bool systematic, const double* targets, bool* handled)
+{
+  *handled = false;
+  SampleSet& a = e->sets[e->cur];
+  SampleSet& b = e->sets[e->cur ^ 1];
+  if (!systematic)
+  {
+    int rc = ensure_limit_table(e, window);
+    if (rc != BPF_OK)
+      return rc;
+  }
+  HIPCHK(e, e->h_fused.reserve(32));
+  if (!e->fused_lds_attr_set)
+  {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_resample_block),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+    e->fused_lds_attr_set = true;
+  }
+  if (!e->d_fused_jump.p)
+  {
+    // draw m takes stream element 2 m + 2: the composed LCG step for that distance, per draw of the window
+    std::vector<FusedJump> jt(kFusedWindow);
+    const uint64_t mask = (1ull << 48) - 1;
+    for (int m = 0; m < kFusedWindow; ++m)
+    {
+      uint64_t a = 1, c = 0, k = 2ull * (uint64_t)m + 2ull;
+      for (int j = 0; k != 0 && j < 48; ++j, k >>= 1)
+        if (k & 1)
+        {
+          a = (a * e->jump.A[j]) & mask;
+          c = (c * e->jump.A[j] + e->jump.C[j]) & mask;
+        }
+      jt[m].a = a;
+      jt[m].c = c;
+    }
+    HIPCHK(e, e->d_fused_jump.reserve(kFusedWindow));
+    HIPCHK(e, hipMemcpy(e->d_fused_jump.p, jt.data(), jt.size() * sizeof(FusedJump), hipMemcpyHostToDevice));
+    HIPCHK(e, e->d_fused_keys.reserve(kFusedWindow));
+    HIPCHK(e, e->d_fused_counter.reserve(1));
+    HIPCHK(e, hipMemset(e->d_fused_counter.p, 0, sizeof(unsigned)));
+  }
+  ResampleBlockArgs A{};
+  A.src = a.dev();
+  A.n_src = e->sample_count;
+  A.cdf = e->d_cdf.p;
+  A.coarse_shift = fused_coarse_shift(A.n_src);
+  A.coarse = (e->cdf_coarse_n == A.n_src) ? e->d_cdf_coarse.p : nullptr;
+  A.dst = b.dev();
+  A.window = window;
+  A.max_samples = e->max_samples;
+  A.systematic = systematic ? 1 : 0;
+  A.targets = targets;
+  A.rng_state = e->rng;
+  A.jump = e->d_fused_jump.p;
+  A.keys = e->d_fused_keys.p;
+  A.counter = e->d_fused_counter.p;
+  A.limit = e->d_kld_limit.p;
+  A.miss_flag = e->d_flags.p;
+  A.thr = e->dist_threshold;
+  A.sc = e->d_scalars.p;
+  A.conv_count = e->d_flags.p + 1;
+  A.result_host = e->h_fused.p;
+  e->fused_generation = (e->fused_generation % 0x3fffffff) + 1;
+  A.generation = e->fused_generation;
+  A.debug = getenv("BPF_DEBUG") != nullptr;
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_resample_block, dim3(blocks_for(window, kFusedDrawsPerBlock)), dim3(1024), kFusedLds,
+                       e->stream, A);
+  }
+  HIPCHK(e, hipGetLastError());
+  // the block publishes its generation in pinned memory when the results are there (a ~25 us kernel)
+  const auto t0 = std::chrono::steady_clock::now();
+  bool seen = false;
+  for (unsigned spins = 0; !seen; ++spins)
+  {
+    seen = __atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) == A.generation;
+    if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+      break;
+    if (!seen)
+      __builtin_ia32_pause();
+  }
+  if (!seen)
+  {
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (__atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) != A.generation)
+      return e->fail(BPF_ERR_HIP, "k_resample_block did not publish its result");
+  }
+  const int* res = e->h_fused.p;
+  if (getenv("BPF_DEBUG"))
+  {
+    fprintf(stderr, "[resample block] window %d M %d leaf %d bins %d status %d levels %d; last block (10 ns ticks): load %d "
+            "dedup %d tree %d scan %d tail %d = %d shader clocks\n", window, res[1], res[2], res[3], res[4], res[5],
+            res[11] - res[9], res[12] - res[11], res[13] - res[12], res[14] - res[13], res[15] - res[14], res[6]);
+    fprintf(stderr, "   block 0 draw phase (if it was not the last block): stage %d search %d gather+key %d fence %d\n",
+            res[28] - res[20], res[29] - res[28], res[30] - res[29], res[31] - res[30]);
+  }
+  if (res[4] != BPF_FUSED_OK)
+    return BPF_OK;
+  e->sample_count = res[1];
+  e->kld_leaf = res[2];
+  e->kld_bins = res[3];
+  e->kld_device_used = true;
+  e->fused_used = 1;
+  e->resample_windows = 1;
+  *handled = true;
+  return BPF_OK;
+}
+
+// The KLD stop rule for the whole candidate stream [0, maxs) on the device (kernels_kld.hpp), keys in
+// e->d_keys (AoS): grows the histogram tree level by level and scans the leaf count.
+// Returns BPF_OK with *stop_out = stop count (or -1: no stop), *leaf_out / *bins_out at the final count;
+// *handled = false when a key does not fit the 64-bit packing or the tree is deeper than the level budget
+// (the caller then replays on the host as before).
+int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out,
+                       bool whole_stream = false)
+{
+  *handled = false;
+  const int n = maxs;
+  if (n >= (1 << 30))
+    return BPF_OK;  // element indices 2v + side are folded as 32-bit tags
+  int rcl = ensure_limit_table(e, n);
+  if (rcl != BPF_OK)
+    return rcl;
   unsigned table = 1024;
   while (table < 2u * (unsigned)n)
     table <<= 1;
@@ -322,6 +507,26 @@ int resample_multinomial(bpf_engine* e, double w_diff)
     if (rcf != BPF_OK)
       return rcf;
     chain = e->d_chain.p;
+  }
+  e->fused_used = 0;
+  {
+    // tracking regime: the previous cycle's stop (+ 25 %) fits one block's window and no recovery draws are due
+    const int w0 = std::min(std::max(1024, std::min(e->window_hint, maxs)), maxs);
+    const bool long_stream0 = e->window_hint >= maxs && maxs >= e->kld_device_min;
+    if (e->fused_resample && w_diff == 0.0 && w0 <= kFusedWindow && !long_stream0)
+    {
+      bool handled = false;
+      int rcb = resample_block(e, w0, false, nullptr, &handled);
+      if (rcb != BPF_OK)
+        return rcb;
+      if (handled)
+      {
+        const int M = e->sample_count;
+        e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)M, e->jump);
+        e->window_hint = std::max(1024, ((M + M / 4) + 1023) / 1024 * 1024);
+        return BPF_OK;
+      }
+    }
   }
   HIPCHK(e, e->d_keys.reserve((size_t)maxs * 3));
   HIPCHK(e, e->d_src_index.reserve((size_t)maxs));
@@ -457,6 +662,7 @@ int resample_systematic(bpf_engine* e, double w_diff)
   SampleSet& a = e->sets[e->cur];
   SampleSet& b = e->sets[e->cur ^ 1];
   const int n = e->sample_count;
+  e->fused_used = 0;
   int count = resample_limit(e->leaf_count, e->min_samples, e->max_samples, e->pop_err, e->pop_z);
   FreeSpaceDev free_space{};
   int num_random = 0;
@@ -509,6 +715,17 @@ int resample_systematic(bpf_engine* e, double w_diff)
       if (t > 1.0)
         t -= 1.0;
     }
+  }
+  if (e->fused_resample && num_random == 0 && count <= kFusedWindow)
+  {
+    // the whole resample as one launch (k_resample_block): selection, the new set's histogram tree, weights,
+    // updateConverged; the targets are read straight from the pinned buffer
+    bool handled = false;
+    int rcb = resample_block(e, count, true, e->h_targets.p, &handled);
+    if (rcb != BPF_OK)
+      return rcb;
+    if (handled)
+      return BPF_OK;
   }
   // the kernel reads the targets straight from the pinned buffer (28 KB for 3.5 k samples) and, like the
   // multinomial draw kernel, leaves the keys in pinned memory behind a generation word

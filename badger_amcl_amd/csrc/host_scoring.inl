@@ -402,7 +402,7 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
 {
   *forced_zero = false;
   e->fused_partials = 0;
-  e->tile_sums_n = -1;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   if (!e->have_map)
     return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
   if (!e->have_lut)

@@ -1,0 +1,786 @@
+// The tracking-regime tail of the headline step in two launches instead of five plus a host round trip:
+//
+//   k_normalize_cdf   ParticleFilter::updateSensor's normalisation (particle_filter.cpp:237-266) AND the resampling
+//                     CDF (:372-375) in one launch: every block normalises its 2048-weight tile, publishes the tile's
+//                     sum, waits for the tiles before it (they were dispatched earlier, so they are running) and
+//                     writes its slice of the CDF.  Same arithmetic, same summation shapes and therefore the same bits
+//                     as k_normalize_fused followed by k_scan_final.
+//   k_resample_block  resampleMultinomial / resampleSystematic (:269-420) for a candidate stream of at most 4096 draws
+//                     in ONE block: drand48 jump-ahead, CDF search, pose gather, histogram keys, then the KLD stop rule
+//                     -- the fork's insertion-order-dependent kd-tree leaf count (pf_kdtree.cpp:97-150) grown level by
+//                     level in LDS exactly as kernels_kld.hpp grows it in HBM for long streams --, the weights 1/M and
+//                     updateConverged (:170-220).  The keys never leave the CU; the host only reads back
+//                     (M, leaf count, bin count) from pinned memory.
+#pragma once
+#include <climits>
+
+#include "kernels_kld.hpp"
+#include "kernels_pf.hpp"
+
+namespace bpf
+{
+
+struct NormCdfArgs
+{
+  double* w;
+  int n;
+  const double* block_partials;  // the scoring kernel's per-block weight sums
+  int n_partials;
+  FilterScalars* sc;
+  double alpha_slow, alpha_fast;
+  double* tile_sums;     // [tiles] normalised-weight sum per 2048-tile
+  unsigned* tile_flags;  // [tiles] generation of the sum stored there
+  unsigned generation;
+  double* cdf;           // [n + 1]
+  double* coarse;        // [((n - 1) >> coarse_shift) + 2]: c[min(k << coarse_shift, n)], what k_resample_block stages
+  int coarse_shift;
+  int* guide;            // CDF guide table (kCdfGuide + 2)
+  int* zero_word;        // the CDF-miss flag of the draw kernels that follow
+};
+
+// grid = tiles (<= 256: thread t of a block fetches the sum of tile t), block = 256
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfArgs A)
+{
+  __shared__ double s_wave[4];
+  __shared__ double s_tiles[BPF_RED_BLOCK];
+  __shared__ double s_tile_off;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  // ---- the total: every block folds the partials with the same fixed tree (k_normalize_fused)
+  double acc = 0.0;
+  for (int i = tid; i < A.n_partials; i += BPF_RED_BLOCK)
+    acc += A.block_partials[i];
+  const double total = block_sum_256(acc, s_wave);
+  if (b == 0 && tid == 0)
+  {
+    FilterScalars* sc = A.sc;
+    sc->v[0] = total;
+    sc->v[6] = total;
+    if (total > 0.0)
+    {
+      const double w_avg = total / A.n;
+      double ws = sc->v[1], wf = sc->v[2];
+      if (ws == 0.0)
+        ws = w_avg;
+      else
+        ws += A.alpha_slow * (w_avg - ws);
+      if (wf == 0.0)
+        wf = w_avg;
+      else
+        wf += A.alpha_fast * (w_avg - wf);
+      sc->v[1] = ws;
+      sc->v[2] = wf;
+    }
+    *A.zero_word = 0;
+  }
+  // ---- normalise the tile; its sum in k_normalize_fused's shape, its running sums in k_scan_final's
+  const size_t base = (size_t)b * BPF_RED_TILE + (size_t)tid * BPF_RED_PER_THREAD;
+  const double uniform = 1.0 / A.n;
+  double v[BPF_RED_PER_THREAD];
+  double tsum = 0.0, run = 0.0;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+  {
+    double x = 0.0;
+    if (base + k < (size_t)A.n)
+    {
+      x = (total > 0.0) ? A.w[base + k] / total : uniform;
+      A.w[base + k] = x;
+      tsum += x;
+    }
+    run += x;
+    v[k] = run;
+  }
+  const double tile = block_sum_256(tsum, s_wave);
+  if (tid == 0)
+  {
+    __hip_atomic_store(&A.tile_sums[b], tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.tile_flags[b], A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- the tiles before this one (blocks are dispatched in index order: they are resident or done)
+  if (tid < b)
+  {
+    while (__hip_atomic_load(&A.tile_flags[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != A.generation)
+      __builtin_amdgcn_s_sleep(1);
+    s_tiles[tid] = __hip_atomic_load(&A.tile_sums[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    double off = 0.0;
+    for (int t = 0; t < b; ++t)  // left to right, as k_scan_final adds them
+      off += s_tiles[t];
+    s_tile_off = off;
+  }
+  const double incl = wave_incl_scan(run);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 63)
+    s_wave[wave] = incl;
+  __syncthreads();
+  double off = s_tile_off;
+  for (int k = 0; k < wave; ++k)
+    off += s_wave[k];
+  off += incl - run;
+  const unsigned cmask = (1u << A.coarse_shift) - 1u;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+    if (base + k < (size_t)A.n)
+    {
+      const unsigned idx = (unsigned)(base + k + 1);
+      A.cdf[idx] = off + v[k];
+      if ((idx & cmask) == 0u)
+        A.coarse[idx >> A.coarse_shift] = off + v[k];
+      else if (idx == (unsigned)A.n)
+        A.coarse[(idx >> A.coarse_shift) + 1] = off + v[k];
+    }
+  if (b == 0 && tid == 0)
+  {
+    A.cdf[0] = 0.0;
+    A.coarse[0] = 0.0;
+  }
+  if (A.guide != nullptr)
+  {
+    double lo_c = (base == 0) ? 0.0 : off;
+#pragma unroll
+    for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+      if (base + k < (size_t)A.n)
+      {
+        const double hi_c = off + v[k];
+        for (int j = (int)ceil(lo_c * (double)kCdfGuide); j <= kCdfGuide && (double)j / (double)kCdfGuide < hi_c; ++j)
+          A.guide[j] = (int)(base + k);
+        if (base + k == (size_t)A.n - 1)
+          for (int j = (int)ceil(hi_c * (double)kCdfGuide); j <= kCdfGuide; ++j)
+            A.guide[j] = A.n;
+        lo_c = hi_c;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFusedWindow = 4096;     // candidate draws one block takes (4 per thread)
+constexpr int kFusedPerThread = 4;
+constexpr int kFusedMaxLevels = 128;   // deeper histogram trees go back to the general path
+constexpr int kFusedMaxBins = 1024;    // distinct histogram bins in the window (one tree key per thread)
+constexpr int kFusedCoarse = 4096;     // entries of the CDF subsample staged in LDS (+ 1)
+// LDS: packed keys 8 B, hash table / tree children / coarse CDF 8 B, first 4 B, staged x and y 16 B per draw
+constexpr size_t kFusedLds = (size_t)kFusedWindow * (8 + 8 + 4 + 16) + 16;
+
+enum
+{
+  BPF_FUSED_OK = 0,
+  BPF_FUSED_NO_STOP = 1,    // no stop inside the window and the window is not the whole stream
+  BPF_FUSED_KEY_RANGE = 2,  // a histogram key outside the 24 + 24 + 16 bit packing
+  BPF_FUSED_TOO_DEEP = 3,
+  BPF_FUSED_TOO_MANY_BINS = 4
+};
+
+struct FusedJump
+{
+  uint64_t a, c;  // x -> a * x + c (mod 2^48) advances the drand48 state by 2 m + 2 elements (draw m)
+};
+
+constexpr int kFusedDrawsPerBlock = 128;  // draw phase: the window is spread over window / 128 blocks (CUs)
+
+struct ResampleBlockArgs
+{
+  ParticlesDev src;   // set a
+  int n_src;
+  const double* cdf;  // [n_src + 1]
+  const double* coarse;  // c[min(k << coarse_shift, n)], k = 0 .. ((n - 1) >> shift) + 1 (nullable: read from cdf)
+  int coarse_shift;   // ((n_src - 1) >> shift) + 1 <= kFusedCoarse
+  ParticlesDev dst;   // set b
+  int window;         // candidate draws 0 .. window - 1, <= kFusedWindow
+  int max_samples;
+  int systematic;     // 1: draw m takes r = targets[m], the set size is `window`, no stop rule
+  const double* targets;
+  uint64_t rng_state;
+  const FusedJump* jump;  // [kFusedWindow]
+  unsigned long long* keys;  // [window] packed histogram keys, draw phase -> tree phase
+  unsigned* counter;  // blocks that finished their draws (0 between launches)
+  const int* limit;   // resampleLimit per leaf count, [0 .. window]
+  int* miss_flag;
+  double thr;         // updateConverged's distance threshold
+  FilterScalars* sc;
+  int* conv_count;
+  volatile int* result_host;  // pinned: [1] M, [2] leaf count, [3] bin count, [4] status, [5] levels, then [0] generation
+  int generation;
+  int debug;          // also copy the phase clocks out ([6], [8 ..])
+};
+
+// which side of node v key i goes to: split axis = largest |delta| between v's key and the first different key f
+// routed through v, earliest axis on ties (pf_kdtree.cpp:133-146); high side if greater on that axis.  Packed keys:
+// the offsets of kld_pack cancel in differences and comparisons.
+__device__ __forceinline__ int fused_side(unsigned long long kv, unsigned long long kf, unsigned long long ki)
+{
+  const int v0 = (int)(kv >> 40), v1 = (int)((kv >> 16) & 0xFFFFFFull), v2 = (int)(kv & 0xFFFFull);
+  const int f0 = (int)(kf >> 40), f1 = (int)((kf >> 16) & 0xFFFFFFull), f2 = (int)(kf & 0xFFFFull);
+  const int i0 = (int)(ki >> 40), i1 = (int)((ki >> 16) & 0xFFFFFFull), i2 = (int)(ki & 0xFFFFull);
+  const int d0 = abs(f0 - v0), d1 = abs(f1 - v1), d2 = abs(f2 - v2);
+  int best = 0, cv = v0, ci = i0;
+  if (d0 > best)
+    best = d0;
+  if (d1 > best)
+  {
+    best = d1;
+    cv = v1;
+    ci = i1;
+  }
+  if (d2 > best)
+  {
+    cv = v2;
+    ci = i2;
+  }
+  return ci > cv ? 1 : 0;
+}
+
+__device__ __forceinline__ int wave_incl_scan_int(int v)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const int o = __shfl_up(v, off, 64);
+    if (lane >= off)
+      v += o;
+  }
+  return v;
+}
+
+// The histogram tree of the window's distinct keys, level by level (kernels_kld.hpp): per level the earliest waiting
+// key on either side of every node becomes that node's child, the others step down to it.  Thread k holds tree key
+// s_list[k] (a draw index).  ONE_WAVE: at most 64 keys, wave 0 runs alone and LDS order within the wave replaces the
+// block barriers.  Returns the number of levels used (kFusedMaxLevels: gave up).
+template <bool ONE_WAVE>
+__device__ __forceinline__ int fused_tree(int my, bool have, const unsigned long long* s_key, int* s_first,
+                                          int* s_child, unsigned* s_nodelta)
+{
+  int cur = (have && my != 0) ? 0 : -1;  // every tree key but the root's (draw 0) waits at the root
+  {
+    int wmin = cur == 0 ? my : INT_MAX;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      wmin = min(wmin, __shfl_xor(wmin, off, 64));
+    if ((threadIdx.x & 63) == 0 && wmin != INT_MAX)
+      atomicMin(&s_first[0], wmin);
+  }
+  if (ONE_WAVE)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  else
+    __syncthreads();
+  const unsigned long long mine = have ? s_key[my] : 0ull;
+  int level = 0;
+  for (; level < kFusedMaxLevels; ++level)
+  {
+    int side = 0, fst = 0;
+    if (cur >= 0)
+    {
+      fst = s_first[cur];
+      side = fused_side(s_key[cur], s_key[fst], mine);
+      atomicMin(&s_child[2 * cur + side], my);
+    }
+    if (ONE_WAVE)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    else
+      __syncthreads();
+    int still = 0;
+    if (cur >= 0)
+    {
+      const int ch = s_child[2 * cur + side];
+      if (ch == my)
+      {
+        cur = -1;  // my is a node now
+        if (fst == my)
+          atomicOr(&s_nodelta[my >> 5], 1u << (my & 31));  // its creation ends the parent's time as a leaf: +1 - 1
+      }
+      else
+      {
+        cur = ch;
+        atomicMin(&s_first[ch], my);
+        still = 1;
+      }
+    }
+    if (ONE_WAVE)
+    {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (__builtin_amdgcn_ballot_w64(still != 0) == 0)
+        break;
+    }
+    else if (!__syncthreads_or(still))
+      break;
+  }
+  return level;
+}
+
+// phase clock (100 MHz constant clock), kept in LDS and copied to the pinned result block [8 + k] at the end (a store
+// to host memory in the middle would stall the next barrier); read with BPF_DEBUG only
+#define BPF_FUSED_STAMP(k)                                                   \
+  do                                                                         \
+  {                                                                          \
+    if (threadIdx.x == 0)                                                    \
+      s_stamp[k] = (int)(unsigned)wall_clock64();                            \
+  } while (0)
+
+// grid = ceil(window / 128) blocks of 1024 threads.  Draw phase: block b takes draws 128 b .. 128 b + 127 (its first two
+// waves, one draw per lane; a CU's texture path takes about one cache line per clock, so 4096 random gathers want to be
+// spread over many CUs).  The block that finishes last then holds every key and runs the rest alone.
+__global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs A)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int W = kFusedWindow;
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);    // [W]
+  int* s_hash = reinterpret_cast<int*>(smem + (size_t)W * 8);                 // [2 W]; first the coarse CDF, last the children
+  double* s_coarse = reinterpret_cast<double*>(s_hash);                       // [W + 1] (the 16-byte pad takes entry W)
+  int* s_child = s_hash;
+  int* s_first = reinterpret_cast<int*>(smem + (size_t)W * 16 + 16);          // [W]
+  double* s_x = reinterpret_cast<double*>(smem + (size_t)W * 20 + 16);        // [W]
+  double* s_y = s_x + W;                                                      // [W]
+  __shared__ int s_stop, s_bad, s_leaf, s_bins, s_count, s_levels, s_last;
+  __shared__ int s_stamp[16];
+  __shared__ int s_wx[16];
+  __shared__ int s_limit[kFusedMaxBins + 1];
+  __shared__ int s_list[kFusedMaxBins];
+  __shared__ unsigned s_nodelta[W / 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int Q = kFusedPerThread;
+  constexpr int kHashMask = 2 * W - 1;
+  const bool stamps = blockIdx.x == 0;
+  if (stamps)
+    BPF_FUSED_STAMP(0);
+
+  // ================================================================== draw phase (every block)
+  const double* __restrict__ c = A.cdf;
+  const int n = A.n_src;
+  const int shift = A.coarse_shift;
+  const int n_coarse = ((n - 1) >> shift) + 1;  // brackets; entry k = c[min(k << shift, n)], k = 0 .. n_coarse
+  if (A.coarse != nullptr)
+    for (int k = tid; k <= n_coarse; k += 1024)
+      s_coarse[k] = A.coarse[k];
+  else
+    for (int k = tid; k <= n_coarse; k += 1024)
+      s_coarse[k] = c[min(k << shift, n)];
+  // draw m takes stream element 2m + 2 (element 2m + 1 is the test against w_diff = 0, particle_filter.cpp:383-393)
+  const int m_draw = blockIdx.x * kFusedDrawsPerBlock + tid;
+  const bool drawing = tid < kFusedDrawsPerBlock && m_draw < A.window;
+  double r = 0.0;
+  if (drawing)
+  {
+    if (A.systematic)
+      r = A.targets[m_draw];
+    else
+    {
+      const FusedJump J = A.jump[m_draw];
+      r = ldexp((double)((J.a * A.rng_state + J.c) & ((1ull << 48) - 1)), -48);
+    }
+  }
+  __syncthreads();
+  if (stamps)
+    BPF_FUSED_STAMP(8);
+  // CDF search (first i with c[i] <= r < c[i+1], :394-398): bracket from the staged subsample, then inside it
+  __shared__ int s_brk[kFusedDrawsPerBlock];
+  double* s_vals = s_x;  // [draws per block][32] (the pose staging area is idle in this phase)
+  static_assert(kFusedDrawsPerBlock * 32 <= 2 * kFusedWindow, "bracket staging must fit the s_x / s_y area");
+  int lo = 0;
+  bool miss = false;
+  if (drawing)
+  {
+    int hi = n_coarse;
+    miss = !(r < s_coarse[n_coarse]) || !(s_coarse[0] <= r);
+    if (miss)
+      atomicExch(A.miss_flag, 1);  // reference: ROS_ASSERT(i < sample_count), particle_filter.cpp:399
+    else
+      while (hi - lo > 1)
+      {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (s_coarse[mid] <= r)
+          lo = mid;
+        else
+          hi = mid;
+      }
+    lo = lo << shift;
+    s_brk[tid] = miss ? -1 : lo;
+  }
+  else if (tid < kFusedDrawsPerBlock)
+    s_brk[tid] = -1;
+  int i_sel = n - 1;
+  if (shift <= 5)
+  {
+    // the block's 128 brackets (at most 32 values = 256 bytes each, aligned) in ONE round, eight threads per bracket
+    // and 32 bytes per thread, then the bisection runs in LDS (d_cdf has the slack for a bracket that ends past n)
+    __syncthreads();
+    for (int t = tid; t < kFusedDrawsPerBlock * 8; t += 1024)
+    {
+      const int j = t >> 3, part = t & 7;
+      const int base = s_brk[j];
+      if (base >= 0 && part * 4 < (1 << shift))
+      {
+        const double4 v = *reinterpret_cast<const double4*>(c + base + part * 4);
+        *reinterpret_cast<double4*>(s_vals + j * 32 + part * 4) = v;
+      }
+    }
+    __syncthreads();
+    if (drawing && !miss)
+    {
+      const double* vals = s_vals + tid * 32;
+      int l = 0, h = min(1 << shift, n - lo);  // vals[l] <= r < vals[h] (vals[h] = c[lo + h], the next bracket's first)
+      while (h - l > 1)
+      {
+        const int mid = l + ((h - l) >> 1);
+        if (vals[mid] <= r)
+          l = mid;
+        else
+          h = mid;
+      }
+      i_sel = lo + l;
+    }
+  }
+  else if (drawing && !miss)
+  {
+    int hi = min(lo + (1 << shift), n);
+    while (hi - lo > 1)
+    {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (c[mid] <= r)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    i_sel = lo;
+  }
+  if (stamps)
+    BPF_FUSED_STAMP(9);
+  if (drawing)
+  {
+    const int i = i_sel;
+    const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
+    A.dst.x[m_draw] = x;
+    A.dst.y[m_draw] = y;
+    A.dst.th[m_draw] = th;
+    int key[3];
+    pose_key(x, y, th, key);
+    unsigned long long pk1;
+    if (!kld_pack(key, &pk1))
+      pk1 = kKldEmpty;  // reported by the tree phase
+    A.keys[m_draw] = pk1;
+    if (stamps)
+      BPF_FUSED_STAMP(10);
+  }
+  __threadfence();
+  __syncthreads();
+  if (stamps)
+    BPF_FUSED_STAMP(11);
+  if (tid == 0)
+  {
+    const unsigned prev = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == gridDim.x - 1;
+    if (s_last)
+      __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last)
+  {
+    if (stamps && tid == 0 && A.debug)
+    {
+      for (int k = 8; k < 12; ++k)
+        A.result_host[20 + k] = s_stamp[k];  // diagnostics only: block 0's draw sub-phases
+      A.result_host[20] = s_stamp[0];
+    }
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  BPF_FUSED_STAMP(1);
+  const long long shader_clk0 = clock64();
+
+  // ================================================================== the last block: every draw of the window
+  for (int k = tid; k <= kFusedMaxBins; k += 1024)
+    s_limit[k] = (k <= A.window && !A.systematic) ? A.limit[k] : INT_MAX;
+  for (int s = tid; s < W; s += 1024)
+    s_first[s] = INT_MAX;
+  for (int s = tid; s < W / 32; s += 1024)
+    s_nodelta[s] = 0u;
+  for (int s = tid; s < 2 * W; s += 1024)
+    s_hash[s] = INT_MAX;  // (the coarse CDF is done with: every thread passed the barriers above)
+  if (tid == 0)
+  {
+    s_stop = INT_MAX;
+    s_bad = 0;
+    s_leaf = 0;
+    s_bins = 0;
+    s_count = 0;
+    s_levels = 0;
+  }
+  // thread t owns draws m = 4t .. 4t + 3 from here on
+  const int m_base = tid * Q;
+  bool act[Q];
+  unsigned long long pk[Q];
+  {
+    bool bad_key = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      const int m = m_base + q;
+      act[q] = m < A.window;
+      pk[q] = act[q] ? __hip_atomic_load(&A.keys[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kKldEmpty;
+      const double x = act[q] ? __hip_atomic_load(&A.dst.x[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      const double y = act[q] ? __hip_atomic_load(&A.dst.y[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      if (act[q])
+      {
+        bad_key |= pk[q] == kKldEmpty;
+        s_key[m] = pk[q];
+        s_x[m] = x;
+        s_y[m] = y;
+      }
+    }
+    __syncthreads();  // s_bad = 0 is in place
+    if (bad_key)
+      s_bad = BPF_FUSED_KEY_RANGE;
+  }
+  __syncthreads();
+  const bool usable = s_bad == 0;
+  BPF_FUSED_STAMP(3);
+
+  // ---- repeated keys fold onto their first occurrence (PFKDTree::insertNode: equal key -> value +=):
+  // open-addressing table of draw indices, a slot holds the earliest draw with its key
+  bool is_first[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    is_first[q] = false;
+  if (usable)
+  {
+    int slot[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      slot[q] = 0;
+      if (!act[q])
+        continue;
+      const int m = m_base + q;
+      unsigned h = (unsigned)((pk[q] * 0x9E3779B97F4A7C15ull) >> 40) & kHashMask;
+      for (;;)
+      {
+        int held = *reinterpret_cast<volatile int*>(&s_hash[h]);
+        if (held == INT_MAX)
+        {
+          held = atomicCAS(&s_hash[h], INT_MAX, m);
+          if (held == INT_MAX)
+            break;
+        }
+        if (s_key[held] == pk[q])
+        {
+          atomicMin(&s_hash[h], m);
+          break;
+        }
+        h = (h + 1) & kHashMask;
+      }
+      slot[q] = (int)h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      is_first[q] = act[q] && s_hash[slot[q]] == m_base + q;
+      if (is_first[q])
+      {
+        const int pos = atomicAdd(&s_count, 1);
+        if (pos < kFusedMaxBins)
+          s_list[pos] = m_base + q;
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < 2 * W; s += 1024)
+      s_child[s] = INT_MAX;
+    __syncthreads();
+  }
+  const int n_bins = s_count;
+  BPF_FUSED_STAMP(4);
+
+  // ---- the tree
+  if (usable && n_bins <= kFusedMaxBins)
+  {
+    const bool have = tid < n_bins;
+    const int my = have ? s_list[tid] : INT_MAX;
+    if (n_bins <= 64)
+    {
+      if (wave == 0)
+      {
+        const int lv = fused_tree<true>(my, have, s_key, s_first, s_child, s_nodelta);
+        // The stop rule straight from the (at most 64) tree keys, without a scan over the draws: the leaf count only
+        // changes at a key's first draw m_k, so between two such draws it is constant and the first draw of that
+        // stretch with m + 1 > resampleLimit(leaves) (particle_filter.cpp:416) is max(m_k, limit) -- if the stretch
+        // is that long.  Every lane ranks its key against all others (values through v_readlane).
+        const int mk = have ? my : INT_MAX;
+        const int dk = (have && !((s_nodelta[my >> 5] >> (my & 31)) & 1u)) ? 1 : 0;
+        int leaf_k = 0, bins_k = 0, next_k = A.window;
+        for (int j = 0; j < n_bins; ++j)
+        {
+          const int mj = __builtin_amdgcn_readlane(mk, j);
+          const int dj = __builtin_amdgcn_readlane(dk, j);
+          leaf_k += (mj <= mk) ? dj : 0;
+          bins_k += (mj <= mk) ? 1 : 0;
+          next_k = (mj > mk) ? min(next_k, mj) : next_k;
+        }
+        int cand = INT_MAX;
+        if (have && !A.systematic)
+        {
+          const int first_over = max(mk, s_limit[min(leaf_k, kFusedMaxBins)]);
+          if (first_over < next_k)
+            cand = first_over + 1;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+          cand = min(cand, __shfl_xor(cand, off, 64));
+        const int M1 = (cand == INT_MAX ? A.window : cand) - 1;  // the last draw of the new set
+        if (have && mk <= M1 && M1 < next_k)
+        {
+          s_leaf = leaf_k;
+          s_bins = bins_k;
+        }
+        if (tid == 0)
+        {
+          s_levels = lv;
+          s_stop = cand;
+        }
+      }
+    }
+    else
+    {
+      const int lv = fused_tree<false>(my, have, s_key, s_first, s_child, s_nodelta);
+      if (tid == 0)
+        s_levels = lv;
+    }
+  }
+  else if (usable && tid == 0)
+    s_bad = BPF_FUSED_TOO_MANY_BINS;
+  __syncthreads();
+  if (s_levels >= kFusedMaxLevels && tid == 0)
+    s_bad = BPF_FUSED_TOO_DEEP;
+  BPF_FUSED_STAMP(5);
+
+  // ---- more than 64 bins: leaf / bin count after every draw by prefix sums (both counts travel in one word, leaves
+  // low, bins << 16: each stays below 4097) and the first draw with m + 1 > resampleLimit(leaves)
+  const bool by_scan = !(usable && n_bins <= 64);
+  int pxy[Q];
+  int bxy = 0;
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    pxy[q] = 0;
+  if (by_scan)
+  {
+    int sxy = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      const int m = m_base + q;
+      if (is_first[q])
+        sxy += (1 << 16) + (((s_nodelta[m >> 5] >> (m & 31)) & 1u) ? 0 : 1);
+      pxy[q] = sxy;
+    }
+    const int ixy = wave_incl_scan_int(sxy);
+    if (lane == 63)
+      s_wx[wave] = ixy;
+    __syncthreads();
+    bxy = ixy - sxy;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      bxy += (k < wave) ? s_wx[k] : 0;
+  }
+  if (!A.systematic && by_scan)
+  {
+    int stop = INT_MAX;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      if (act[q] && stop == INT_MAX &&
+          m_base + q + 1 > s_limit[min((bxy + pxy[q]) & 0xFFFF, kFusedMaxBins)])  // particle_filter.cpp:416
+        stop = m_base + q + 1;
+    if (stop != INT_MAX)
+      atomicMin(&s_stop, stop);
+  }
+  __syncthreads();
+  int M = s_stop;
+  int status = s_bad;
+  if (M == INT_MAX)
+  {
+    M = A.window;
+    // no stop: fine when the window is the loop's own bound, sample_count < max_samples (:381)
+    if (!A.systematic && A.window < A.max_samples && status == 0)
+      status = BPF_FUSED_NO_STOP;
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (by_scan && m_base + q == M - 1)
+    {
+      s_leaf = (bxy + pxy[q]) & 0xFFFF;
+      s_bins = (bxy + pxy[q]) >> 16;
+    }
+  __syncthreads();
+  BPF_FUSED_STAMP(6);
+
+  // ---- weights 1 / M (:409,458-462) and updateConverged (:170-220) in k_resample_tail_small's summation shape,
+  // from the poses staged in LDS
+  if (status == 0)
+  {
+    const double weight = 1.0 / (double)M;
+    double ax = 0.0, ay = 0.0;
+    for (int i = tid; i < M; i += 1024)
+    {
+      A.dst.w[i] = weight;
+      ax += s_x[i];
+      ay += s_y[i];
+    }
+    ax = wave_sum(ax);
+    ay = wave_sum(ay);
+    double* s_px = reinterpret_cast<double*>(s_key);  // the keys are done with
+    double* s_py = s_px + 16;
+    int* s_pc = reinterpret_cast<int*>(s_py + 16);
+    if (lane == 0)
+    {
+      s_px[wave] = ax;
+      s_py[wave] = ay;
+    }
+    __syncthreads();
+    double sxx = 0.0, syy = 0.0;
+    for (int k = 0; k < 16; ++k)
+    {
+      sxx += s_px[k];
+      syy += s_py[k];
+    }
+    const double mx = sxx / M, my = syy / M;
+    int cnt = 0;
+    for (int i = tid; i < M; i += 1024)
+      if (fabs(s_x[i] - mx) <= A.thr && fabs(s_y[i] - my) <= A.thr)
+        cnt++;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0)
+      s_pc[wave] = cnt;
+    __syncthreads();
+    if (tid == 0)
+    {
+      int tot = 0;
+      for (int k = 0; k < 16; ++k)
+        tot += s_pc[k];
+      *A.conv_count = tot;
+      A.sc->v[3] = sxx;
+      A.sc->v[4] = syy;
+    }
+  }
+  BPF_FUSED_STAMP(7);
+  if (tid == 0)
+  {
+    volatile int* out = A.result_host;
+    if (A.debug)
+    {
+      out[6] = (int)(clock64() - shader_clk0);
+      for (int k = 0; k < 12; ++k)
+        out[8 + k] = s_stamp[k];
+    }
+    out[1] = M;
+    out[2] = s_leaf;
+    out[3] = s_bins;
+    out[4] = status;
+    out[5] = s_levels;
+    __threadfence_system();
+    __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+}  // namespace bpf

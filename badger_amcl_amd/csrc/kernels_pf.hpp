@@ -199,12 +199,11 @@ __global__ void k_copy4(ParticlesDev dst, ParticlesDev src, int n)
   dst.w[i] = src.w[i];
 }
 
-// Tail of updateResample for a small resampled set (one block): weights 1/M
+// Tail of updateResample for a small resampled set (one block of 1024 threads): weights 1/M
 // (particle_filter.cpp:409,458-462) and updateConverged (:170-220).
-__global__ __launch_bounds__(1024) void k_resample_tail_small(const double* __restrict__ x,
-                                                             const double* __restrict__ y,
-                                                             double* __restrict__ w, int n, double thr,
-                                                             FilterScalars* sc, int* __restrict__ count_out)
+__device__ __forceinline__ void resample_tail_body(const double* __restrict__ x, const double* __restrict__ y,
+                                                   double* __restrict__ w, int n, double thr, FilterScalars* sc,
+                                                   int* __restrict__ count_out)
 {
   __shared__ double s_x[16], s_y[16];
   __shared__ int s_c[16];
@@ -251,6 +250,14 @@ __global__ __launch_bounds__(1024) void k_resample_tail_small(const double* __re
     sc->v[3] = sx;
     sc->v[4] = sy;
   }
+}
+
+__global__ __launch_bounds__(1024) void k_resample_tail_small(const double* __restrict__ x,
+                                                             const double* __restrict__ y,
+                                                             double* __restrict__ w, int n, double thr,
+                                                             FilterScalars* sc, int* __restrict__ count_out)
+{
+  resample_tail_body(x, y, w, n, thr, sc, count_out);
 }
 
 // folds the scoring kernel's per-block weight partials into scalars[slot] (sharded path: the local total)

@@ -190,9 +190,13 @@ enum
   BPF_OPT_WINDOW_PATH = 2,  /* default 0: 1 allows the LDS-window scoring kernels (device-side switch) */
   BPF_OPT_KLD_DEVICE_MIN = 3, /* default 8192: candidate draws left after the first window from which the KLD stop
                                * rule (ordered kd-tree replay) runs on the device instead of the host; 0 = never */
-  BPF_OPT_GRADED_SHARES = 4   /* default 1: the scoring kernel's waves own particle shares graded by the placement
+  BPF_OPT_GRADED_SHARES = 4,  /* default 1: the scoring kernel's waves own particle shares graded by the placement
                                * round of their block; 0 = equal shares.  Results do not
                                * depend on it beyond the summation order of the weight total. */
+  BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
+                               * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
+                               * updateConverged); 0 = the separate launches with the host's ordered replay.
+                               * Same results either way. */
 };
 int bpf_set_option(bpf_engine* e, int option, int value);
 /* cells visited by calcRange walks since the last reset (BPF_OPT_COUNT_CELLS) */
@@ -211,7 +215,8 @@ typedef struct
   int last_status;        /* BPF_* of the last update_sensor / update_resample */
   int resample_windows;   /* candidate-draw windows used by the last multinomial resample */
   long long evals;        /* particle-beam evaluations of the last sensor update */
-  int kld_on_device;      /* 1 if the last multinomial resample ran the KLD stop rule on the device */
+  int kld_on_device;      /* where the last resample's histogram tree was grown: 0 host (ordered replay), 1 device,
+                           * level-synchronous in HBM (long streams), 2 device, inside the one-block resample kernel */
   int reserved;
 } bpf_pf_state;
 int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out);

@@ -503,3 +503,85 @@ def test_lds_window_scoring_path_matches_oracle(engine, orc):
     bad = rel_err(got[:, 3], opf.samples[:16384, 3]) > W_TOL
     assert bad.sum() <= _knife_edge_budget(16384 * 1081)
     assert plan["chunks_total"] == 17 and plan["used_window"], plan  # the device-side switch took the windows
+
+
+@pytest.mark.parametrize("resampler", [0, 1])
+@pytest.mark.parametrize("cloud,n,min_s,pop", [("converged", 20000, 100, None), ("converged", 3000, 100, None),
+                                                ("mixture", 2500, 500, (0.05, 0.99)), ("spread", 1500, 10, None),
+                                                ("converged", 100000, 100, None)])
+def test_one_block_resample_equals_the_general_path_and_the_oracle(engine, orc, cloud, n, min_s, pop, resampler):
+    """BPF_OPT_FUSED_RESAMPLE (default on): normalise + CDF in one launch and, when the candidate stream fits 4096
+    draws, the whole resample in one single-block launch with the histogram tree grown in LDS.  Three cycles (the
+    second and third start from the window hint the previous one left); against the separate launches with the
+    host's ordered replay (must be bit-identical: set, counts, RNG state, convergence) and against the oracle."""
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    size = 2000 if n == 100000 else 400
+    beams = 181 if n == 100000 else 61
+    sc_ = Scenario(orc, size=size, n=n, beams=beams, cloud=cloud)
+    runs = {}
+    for mode in (1, 0):
+        engine.set_option(hpf.OPT_FUSED_RESAMPLE, mode)
+        try:
+            m, sc, pf, data = sc_.gpu_objects(engine, beams, "lf", min_samples=min_s, seed=19)
+            pf.setResampleModel(resampler)
+            if pop:
+                pf.setPopulationSizeParameters(*pop)
+            log = []
+            for cycle in range(3):
+                sc.updateSensor(pf, data)
+                before, st0, rng0 = pf.getCurrentSet().samples, pf.getState(), pf.getRngState()
+                pf.updateResample()
+                st1 = pf.getState()
+                log.append((before, st0, rng0, pf.getCurrentSet().samples, st1, pf.getRngState()))
+            runs[mode] = log
+        finally:
+            engine.set_option(hpf.OPT_FUSED_RESAMPLE, 1)
+    used_block = 0
+    for cycle in range(3):
+        b1, s01, r01, a1, s1, r1 = runs[1][cycle]
+        b0, s00, r00, a0, s0, r0 = runs[0][cycle]
+        assert np.array_equal(b1, b0) and s01.total == s00.total and s01.w_slow == s00.w_slow, cycle
+        assert np.array_equal(a1, a0) and r1 == r0, cycle
+        assert (s1.sample_count, s1.leaf_count, s1.bin_count, s1.converged) == \
+               (s0.sample_count, s0.leaf_count, s0.bin_count, s0.converged), cycle
+        assert s1.percent_converged == s0.percent_converged
+        assert s0.kld_on_device in (0, 1)
+        used_block += s1.kld_on_device == 2
+        opf = orc.ParticleFilter(min_s, n, 0.0, 0.0, 85.0)
+        opf.pf.rng = r01
+        opf.set_resample_model(resampler)
+        opf.pf.w_slow, opf.pf.w_fast = s01.w_slow, s01.w_fast  # 0 / 0 would make w_diff NaN (SURVEY appendix A.15)
+        if pop:
+            opf.set_population_size_parameters(*pop)
+        opf.set_samples(b1, leaf_count=s01.leaf_count)
+        out = opf.update_resample()
+        assert out.status == 0
+        M = out.sample_count
+        assert (s1.sample_count, s1.leaf_count, s1.bin_count) == (M, out.leaf_count, out.node_count), cycle
+        assert np.array_equal(a1[:, :3], opf.samples[:M, :3]) and np.all(a1[:, 3] == 1.0 / M)
+        assert r1 == opf.pf.rng and s1.converged == out.converged
+    # the one-block kernel really ran (a first cycle beyond its window may not use it; the systematic resampler's
+    # count follows the previous set's leaf count and can stay above 4096 for the first cycles of a large set)
+    assert used_block >= (2 if resampler == 0 else (1 if n <= 4096 else 0))
+
+
+def test_one_block_resample_declines_keys_beyond_its_packing(engine, orc):
+    """Poses 5e6 m from the origin: the histogram key floor(x / 0.5) does not fit 24 bits, the one-block kernel
+    reports it and the general path (host replay, 32-bit keys) takes over with the same result as the oracle."""
+    sc_ = Scenario(orc, size=200, n=2000, beams=61, cloud="converged")
+    m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf", min_samples=100, seed=23)
+    far = sc_.samples.copy()
+    far[:, 0] += 5.0e6
+    far[:, 3] /= far[:, 3].sum()
+    pf.initWithSamples(far)
+    rng0 = pf.getRngState()
+    pf.updateResample()
+    st = pf.getState()
+    opf = orc.ParticleFilter(100, 2000, 0.0, 0.0, 85.0)
+    opf.pf.rng = rng0
+    opf.set_samples(far)
+    out = opf.update_resample()
+    assert st.kld_on_device == 0
+    assert (st.sample_count, st.leaf_count) == (out.sample_count, out.leaf_count)
+    assert np.array_equal(pf.getCurrentSet().samples[:, :3], opf.samples[:out.sample_count, :3])
