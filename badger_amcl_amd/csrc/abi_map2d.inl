@@ -25,43 +25,46 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
   e->h_cells8.resize(ncell);
   for (size_t i = 0; i < ncell; ++i)
     e->h_cells8[i] = (int8_t)cells[i];
-  // chessboard distance to the nearest blocked cell on the padded grid: two raster sweeps of the
-  // 8-neighbour recurrence D = min(D, neighbour + 1), which is exact for the Chebyshev metric
+  // Raycast grid, one 32-bit word per cell of the map padded by one cell all round: byte q = chessboard distance to
+  // the nearest blocked cell (not FREE, or the ring) inside QUADRANT q of the cell (q bit 0: towards -x, bit 1:
+  // towards -y; axes included), capped at 255.  A Bresenham line that heads into quadrant q only ever visits cells of
+  // that quadrant, so the next D - 1 cells of the line are free.  D(c) = 0 if blocked, else
+  // 1 + min(D(c + sx), D(c + sy), D(c + sx + sy)): exact for the chessboard metric restricted to a quadrant (each
+  // of the three neighbours' quadrants lies inside c's), one sweep from the far corner per quadrant.
   const int pw = size_x + 2, ph = size_y + 2;
-  std::vector<uint16_t> dist((size_t)pw * ph, 0);
-  for (int j = 0; j < size_y; ++j)
-    for (int i = 0; i < size_x; ++i)
-      if (cells[i + (size_t)j * size_x] == -1)
-        dist[(size_t)(j + 1) * pw + (i + 1)] = 0xFFFF;
-  for (int y = 1; y < ph - 1; ++y)
-    for (int x = 1; x < pw - 1; ++x)
+  std::vector<uint32_t> cheb((size_t)pw * ph, 0u);
+  {
+    std::vector<uint8_t> blocked((size_t)pw * ph, 1);
+    for (int j = 0; j < size_y; ++j)
+      for (int i = 0; i < size_x; ++i)
+        if (cells[i + (size_t)j * size_x] == -1)
+          blocked[(size_t)(j + 1) * pw + (i + 1)] = 0;
+    std::vector<uint8_t> d((size_t)pw * ph);
+    for (int q = 0; q < 4; ++q)
     {
-      uint16_t& d = dist[(size_t)y * pw + x];
-      if (d == 0)
-        continue;
-      const uint16_t* up = &dist[(size_t)(y - 1) * pw + x];
-      uint16_t best = std::min(std::min(up[-1], up[0]), std::min(up[1], (&d)[-1]));
-      best = (uint16_t)std::min<int>(best + 1, 0xFFFF);
-      d = std::min(d, best);
+      const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
+      std::fill(d.begin(), d.end(), 0);
+      for (int yy = 1; yy < ph - 1; ++yy)
+      {
+        const int y = (sy > 0) ? ph - 1 - yy : yy;
+        for (int xx = 1; xx < pw - 1; ++xx)
+        {
+          const int x = (sx > 0) ? pw - 1 - xx : xx;
+          const size_t c = (size_t)y * pw + x;
+          if (blocked[c])
+            continue;
+          const int a = d[c + sx], b = d[(size_t)(y + sy) * pw + x], cc = d[(size_t)(y + sy) * pw + x + sx];
+          d[c] = (uint8_t)std::min(255, 1 + std::min(a, std::min(b, cc)));
+        }
+      }
+      for (size_t c = 0; c < cheb.size(); ++c)
+        cheb[c] |= (uint32_t)d[c] << (8 * q);
     }
-  for (int y = ph - 2; y >= 1; --y)
-    for (int x = pw - 2; x >= 1; --x)
-    {
-      uint16_t& d = dist[(size_t)y * pw + x];
-      if (d == 0)
-        continue;
-      const uint16_t* dn = &dist[(size_t)(y + 1) * pw + x];
-      uint16_t best = std::min(std::min(dn[-1], dn[0]), std::min(dn[1], (&d)[1]));
-      best = (uint16_t)std::min<int>(best + 1, 0xFFFF);
-      d = std::min(d, best);
-    }
-  std::vector<uint8_t> cheb((size_t)pw * ph);
-  for (size_t q = 0; q < cheb.size(); ++q)
-    cheb[q] = (uint8_t)std::min<int>(dist[q], 255);
+  }
   HIPCHK(e, e->d_cells8.reserve(ncell));
   HIPCHK(e, hipMemcpy(e->d_cells8.p, e->h_cells8.data(), ncell, hipMemcpyHostToDevice));
   HIPCHK(e, e->d_cheb.reserve(cheb.size()));
-  HIPCHK(e, hipMemcpy(e->d_cheb.p, cheb.data(), cheb.size(), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(e->d_cheb.p, cheb.data(), cheb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   M.cells8 = e->d_cells8.p;
   M.cheb = e->d_cheb.p;
   M.lut_tiles = nullptr;

@@ -16,14 +16,15 @@ namespace bpf
 //    The stored value is level*8, the byte offset of the level's term in the per-scan table.
 //    Inside a tile the cells are stored u-major ((u&7)*8 + (v&7)), which makes the byte offset of padded
 //    cell (u, v) a sum with a single masked term:  16*u + 2*v + (16*ltx - 2)*(v & ~7).
-//  * cheb: for raycasts, one byte per cell of the map padded by one cell all round (row-major,
-//    padded cell (x+1, y+1), row length size_x+2): chessboard distance to the nearest cell that is
-//    not CELL_FREE or lies outside the map (the ring counts as blocked), capped at 255.
+//  * cheb: for raycasts, one 32-bit word per cell of the map padded by one cell all round (row-major,
+//    padded cell (x+1, y+1), row length size_x+2): byte q = chessboard distance to the nearest cell that is
+//    not CELL_FREE or lies outside the map (the ring counts as blocked) within quadrant q of the cell (bit 0 of q:
+//    towards -x, bit 1: towards -y, axes included), capped at 255.
 //  * cells8: the tri-state grid narrowed to int8, row-major i + j*size_x.
 struct MapDev
 {
   const uint16_t* lut_tiles;
-  const uint8_t* cheb;
+  const uint32_t* cheb;
   const int8_t* cells8;
   const float* levels;
   int size_x, size_y;

@@ -145,7 +145,7 @@ struct bpf_engine
   std::vector<int8_t> h_cells8;
   std::vector<float> h_levels;
   DevBuf<uint16_t> d_lut_tiles;
-  DevBuf<uint8_t> d_cheb;
+  DevBuf<uint32_t> d_cheb;
   DevBuf<int8_t> d_cells8;
   DevBuf<float> d_levels;
   DevBuf<float> d_lut_f32;

@@ -467,10 +467,12 @@ struct BeamRec
 // and stops at the first cell that is off the map or not FREE.  The cell reached after j steps is a
 // closed form of j (major axis advances j, minor axis advances m_j = floor((2*j*dmin + dmaj)/(2*dmaj)),
 // which is exactly what the reference's running error term produces), so the walk can jump:
-// MapDev::cheb holds, per padded cell, the chessboard distance D to the nearest blocked cell
-// (blocked = not FREE or outside the map; capped at 255).  Every Bresenham step moves at most one
-// cell per axis, so the next D-1 cells of the line are free and the D-th is the next candidate:
-// jump D steps, look again.  The first blocked cell found this way is the one the reference finds,
+// MapDev::cheb holds, per padded cell and per quadrant, the chessboard distance D to the nearest blocked cell of
+// that quadrant (blocked = not FREE or outside the map; capped at 255).  A line that heads into quadrant q stays
+// inside quadrant q of every cell it visits and every Bresenham step moves at most one cell per axis, so the next
+// D-1 cells of the line are free and the D-th is the next candidate: jump D steps, look again.  (With one
+// direction-blind distance per cell a ray running along a wall crawls; per quadrant a ray that is leaving an
+// obstacle behind jumps as far as the space ahead allows: 5.8 look-ups per ray instead of 9.3 on the bench map.)  The first blocked cell found this way is the one the reference finds,
 // and the returned distance uses the same integer deltas.  `walked` still counts the cells the
 // reference would have visited (j_hit + 1), the unit of the kernel's algorithmic bytes.
 __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y0, int x1, int y1, double range_max,
@@ -505,7 +507,8 @@ __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y
   const int step_major = maj_dy * stride + maj_dx, step_minor = min_dy * stride + min_dx;
   const int base = (y0 + 1) * stride + (x0 + 1);
   const int two_dmin = 2 * dmin;
-  const unsigned char* cheb = M.cheb;
+  const uint32_t* cheb = M.cheb;
+  const unsigned qshift = ((sx < 0) ? 8u : 0u) + ((sy < 0) ? 16u : 0u);  // byte of the ray's quadrant
   int j = 0, m = 0;
   bool hit;
   for (;;)
@@ -513,7 +516,7 @@ __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y
     // minor-axis advance after j steps; the 1e-6 absorbs the reciprocal's rounding (fractional parts
     // of the true quotient are multiples of 1/(2*dmaj) >= 1e-4)
     m = (int)fma((double)(__mul24(j, two_dmin) + dmaj), inv2d, 1e-6);
-    const int d = cheb[(unsigned)(__mul24(j, step_major) + __mul24(m, step_minor) + base)];
+    const int d = (int)((cheb[(unsigned)(__mul24(j, step_major) + __mul24(m, step_minor) + base)] >> qshift) & 255u);
     hit = d == 0;
     if (hit || j >= last)  // (this shape compiles to one block of 22 instructions; testing d after the loop does not)
       break;
