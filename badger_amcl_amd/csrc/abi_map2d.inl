@@ -93,8 +93,8 @@ int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, cons
   if (!e->have_map)
     return e->fail(BPF_ERR_NOT_CONFIGURED, "no 2-D map set");
   // the walk forms cell offsets with 24-bit multiply-adds and 32-bit offsets (calc_range_skip)
-  if ((long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 31) || e->map.size_x + 3 >= (1 << 23))
-    return e->fail(BPF_ERR_CAPACITY, "calc_range: a map of 2^31 cells or more");
+  if ((long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 30) || e->map.size_x + 3 >= (1 << 21))
+    return e->fail(BPF_ERR_CAPACITY, "calc_range: a map of 2^30 cells or more");
   for (int i = 0; i < n; ++i)
     if (!(std::fabs(max_range[i]) / e->map.resolution < kMaxRayCells))
       return e->fail(BPF_ERR_CAPACITY, "calc_range: max_range beyond 32 760 cells (or not finite)");

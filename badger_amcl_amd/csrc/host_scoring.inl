@@ -1,3 +1,6 @@
+#ifndef BPF_BEAM_BLOCK
+#define BPF_BEAM_BLOCK 512
+#endif
 // Host half of the planar scoring path: scan staging ring, beam / term tables, kernel launches, beam skipping.
 // ------------------------------------------------------------------ scan staging
 int acquire_slot(bpf_engine* e, size_t bytes, ScanSlot** out)
@@ -439,8 +442,8 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     // the ray walk forms cell offsets with 24-bit multiply-adds and 32-bit offsets (calc_range_skip); its error term
     // j * 2 * dmin (j <= dmaj + 1, dmin <= dmaj <= range_max / resolution + 1) must stay below 2^31
     if (!(range_max / e->map.resolution < kMaxRayCells) ||
-        (long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 31) || e->map.size_x + 3 >= (1 << 23))
-      return e->fail(BPF_ERR_CAPACITY, "beam model: range_max beyond 32 760 cells, or a map of 2^31 cells or more");
+        (long long)(e->map.size_x + 2) * (long long)(e->map.size_y + 2) >= (1ll << 30) || e->map.size_x + 3 >= (1 << 21))
+      return e->fail(BPF_ERR_CAPACITY, "beam model: range_max beyond 32 760 cells, or a map of 2^30 cells or more");
     // The beams stay in bearing order: one trip of a wave then casts 64 neighbouring bearings from one pose, which
     // pass much the same cells (measured: 2.73 ms against 2.98 ms with the beams ordered by observed range).
     const size_t bytes = beams.size() * sizeof(BeamRec);
@@ -476,22 +479,30 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
       }
       A.cells_walked = e->d_cells_walked.p;
     }
+    constexpr int kBeamBlock = BPF_BEAM_BLOCK;
+    constexpr int kBeamWaves = kBeamBlock / 64;
     int api_blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, reinterpret_cast<const void*>(&k_score_beam), 256,
-                                                     bytes) != hipSuccess || api_blocks < 1)
+    // rays of at most kIntDivRayCells cells: the integer form of the walk (calc_range_skip)
+    const bool int_div = range_max / e->map.resolution <= (double)kIntDivRayCells;
+    const void* kfn = int_div ? reinterpret_cast<const void*>(&k_score_beam<kBeamBlock, true>)
+                              : reinterpret_cast<const void*>(&k_score_beam<kBeamBlock, false>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, kfn, kBeamBlock, bytes) != hipSuccess || api_blocks < 1)
       api_blocks = 1;
-    const int per_cu = std::max(1, std::min(api_blocks, 6));
+    const int per_cu = std::max(1, std::min(api_blocks, 32 / kBeamWaves));
     // one resident round of blocks; the waves fetch their particles from a counter (k_score_beam), a few at a time
     // so that the round drains evenly: ~16 grabs per wave, at most 16 particles each (100 k particles: 2 per grab;
     // 1, 2 and 4 measure alike, 8 costs 8 %, 16 costs 23 %)
-    A.per_wave = std::max(1, std::min(16, blocks_for(n, e->n_cu * per_cu * 4 * 16)));
-    const int grid = std::max(1, std::min(e->n_cu * per_cu, blocks_for(blocks_for(n, A.per_wave), 4)));
+    A.per_wave = std::max(1, std::min(16, blocks_for(n, e->n_cu * per_cu * kBeamWaves * 16)));
+    const int grid = std::max(1, std::min(e->n_cu * per_cu, blocks_for(blocks_for(n, A.per_wave), kBeamWaves)));
     HIPCHK(e, e->d_beam_counter.reserve(1));
     HIPCHK(e, hipMemsetAsync(e->d_beam_counter.p, 0, sizeof(int), e->stream));
     A.next_particle = e->d_beam_counter.p;
     A.block_partials = nullptr;  // dynamic assignment: the total comes from the fixed-shape sum over the weights
     (void)want_partials;
-    LAUNCH_TIMED(e, BPF_K_SCORE, k_score_beam, dim3(grid), dim3(256), bytes, A);
+    if (int_div)
+      LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_beam<kBeamBlock, true>), dim3(grid), dim3(kBeamBlock), bytes, A);
+    else
+      LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_beam<kBeamBlock, false>), dim3(grid), dim3(kBeamBlock), bytes, A);
     HIPCHK(e, hipGetLastError());
     e->evals_last = (long long)n * (long long)beams.size();
     return release_slot(e, s);

@@ -475,6 +475,12 @@ struct BeamRec
 // obstacle behind jumps as far as the space ahead allows: 5.8 look-ups per ray instead of 9.3 on the bench map.)  The first blocked cell found this way is the one the reference finds,
 // and the returned distance uses the same integer deltas.  `walked` still counts the cells the
 // reference would have visited (j_hit + 1), the unit of the kernel's algorithmic bytes.
+// INT_DIV: the minor-axis advance by a 32-bit fixed-point reciprocal (one v_mul_hi_u32 per look-up instead of two
+// conversions and an fp64 multiply-add); exact while (2 (dmaj + 1) dmin + dmaj) * 2 dmaj < 2^32, i.e. for rays of at
+// most kIntDivRayCells cells -- the host picks the variant per launch from range_max / resolution.
+constexpr int kIntDivRayCells = 1000;
+
+template <bool INT_DIV>
 __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y0, int x1, int y1, double range_max,
                                                   unsigned long long& walked)
 {
@@ -498,27 +504,45 @@ __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y
   double inv2d = __builtin_amdgcn_rcp(two_d);
   inv2d = fma(fma(-two_d, inv2d, 1.0), inv2d, inv2d);
   inv2d = fma(fma(-two_d, inv2d, 1.0), inv2d, inv2d);
+  // INT_DIV: magic = floor(2^32 / D) + 1 for D = 2 dmaj, so that floor(u / D) = mulhi(u, magic) for every u with
+  // u * D < 2^32 (the error magic * D - 2^32 is at most D).  floor(2^32 / D) from the reciprocal, then set right by
+  // one integer multiply (the estimate is within 1 of the true quotient: 2^32 * inv2d is good to ~1e-6 absolute).
+  unsigned magic = 0;
+  if (INT_DIV)
+  {
+    const unsigned D = 2u * (unsigned)dmaj;
+    unsigned q = (unsigned)fma(4294967296.0, inv2d, -0.5);       // floor(2^32 / D) or one less / more
+    const unsigned rem = 0u - q * D;                             // 2^32 - q D (mod 2^32), in [-(D), 2 D) as a signed value
+    q += ((int)rem >= (int)D) ? 1u : 0u;
+    q -= ((int)rem < 0) ? 1u : 0u;
+    magic = q + 1u;
+  }
   const int last = dmaj + 1;  // the reference tests cells j = 0 .. dmaj + 1
   const int stride = M.size_x + 2;
   // The walk itself is kept to a dozen instructions per visited cell (the kernel is bound by its instruction
   // count): the cell after j major and m minor steps sits at base + j * step_major + m * step_minor in the padded
-  // chessboard-distance grid, all three formed once per ray; 24-bit multiply-adds (|step| <= size_x + 3 < 2^23,
-  // j, m <= range_max / resolution + 1, checked where the map is set).
-  const int step_major = maj_dy * stride + maj_dx, step_minor = min_dy * stride + min_dx;
-  const int base = (y0 + 1) * stride + (x0 + 1);
+  // chessboard-distance grid, all three formed once per ray, in BYTES (the grid has one 32-bit word per cell);
+  // 24-bit multiply-adds (4 |step| <= 4 (size_x + 3) < 2^23, j, m <= range_max / resolution + 1, checked where the
+  // map is set).
+  const int step_major = 4 * (maj_dy * stride + maj_dx), step_minor = 4 * (min_dy * stride + min_dx);
+  const int base = 4 * ((y0 + 1) * stride + (x0 + 1));
   const int two_dmin = 2 * dmin;
-  const uint32_t* cheb = M.cheb;
+  const char* cheb = reinterpret_cast<const char*>(M.cheb);
   const unsigned qshift = ((sx < 0) ? 8u : 0u) + ((sy < 0) ? 16u : 0u);  // byte of the ray's quadrant
   int j = 0, m = 0;
   bool hit;
   for (;;)
   {
-    // minor-axis advance after j steps; the 1e-6 absorbs the reciprocal's rounding (fractional parts
-    // of the true quotient are multiples of 1/(2*dmaj) >= 1e-4)
-    m = (int)fma((double)(__mul24(j, two_dmin) + dmaj), inv2d, 1e-6);
-    const int d = (int)((cheb[(unsigned)(__mul24(j, step_major) + __mul24(m, step_minor) + base)] >> qshift) & 255u);
+    // minor-axis advance after j steps, floor((2 j dmin + dmaj) / (2 dmaj)); fp64 variant: the 1e-6 absorbs the
+    // reciprocal's rounding (fractional parts of the true quotient are multiples of 1/(2*dmaj) >= 1e-4)
+    if (INT_DIV)
+      m = (int)__umulhi((unsigned)(__mul24(j, two_dmin) + dmaj), magic);
+    else
+      m = (int)fma((double)(__mul24(j, two_dmin) + dmaj), inv2d, 1e-6);
+    const unsigned off = (unsigned)(__mul24(j, step_major) + __mul24(m, step_minor) + base);
+    const int d = (int)((*reinterpret_cast<const uint32_t*>(cheb + off) >> qshift) & 255u);
     hit = d == 0;
-    if (hit || j >= last)  // (this shape compiles to one block of 22 instructions; testing d after the loop does not)
+    if (hit || j >= last)  // (this shape compiles to one block; testing d after the loop does not)
       break;
     j = min(j + d, last);
   }
@@ -551,12 +575,18 @@ struct BeamModelArgs
 
 // Beam model: calcBeamModel (planar_scanner.cpp:168-234).  Wave = particle, lanes = beams in bearing order (the 64
 // rays of one trip are neighbouring bearings from one pose and pass much the same cells).
-__global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
+#ifndef BPF_BEAM_WAVES_ATTR
+#define BPF_BEAM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
+#endif
+// BLOCK threads share one copy of the scan in LDS (43 KB at 1081 beams): the more waves per copy, the more of them a CU
+// holds.
+template <int BLOCK, bool INT_DIV>
+__global__ __launch_bounds__(BLOCK) BPF_BEAM_WAVES_ATTR void k_score_beam(const BeamModelArgs A)
 {
   extern __shared__ __align__(16) unsigned char smem[];
   BeamRec* s_beams = reinterpret_cast<BeamRec*>(smem);
   const int tid = threadIdx.x;
-  for (int i = tid; i < A.n_beams; i += 256)
+  for (int i = tid; i < A.n_beams; i += BLOCK)
     s_beams[i] = A.beams[i];
   __syncthreads();
 
@@ -601,7 +631,7 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
         const double sa = s * B.cb + c * B.sb;
         const int x1 = world_to_cell_rcp(ox + A.range_max * ca, M.origin_x, M.resolution, A.inv_resolution, M.half_x);
         const int y1 = world_to_cell_rcp(oy + A.range_max * sa, M.origin_y, M.resolution, A.inv_resolution, M.half_y);
-        const double map_range = calc_range_skip(M, sx0, sy0, x1, y1, A.range_max, walked);
+        const double map_range = calc_range_skip<INT_DIV>(M, sx0, sy0, x1, y1, A.range_max, walked);
         const double z = B.obs - map_range;
         double pz = 0.0;
         pz += A.z_hit * exp(-(z * z) / A.denom);
@@ -624,16 +654,8 @@ __global__ __launch_bounds__(256) void k_score_beam(const BeamModelArgs A)
       wsum += w;
     }
   }
-  if (A.block_partials != nullptr)
-  {
-    __shared__ double s_part[4];
-    const double ws = wave_sum(wsum);
-    if (lane == 0)
-      s_part[wave] = ws;
-    __syncthreads();
-    if (tid == 0)
-      A.block_partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-  }
+  (void)wsum;
+  (void)wave;
   if (A.cells_walked != nullptr)
   {
     // per-wave total, one atomic per wave
@@ -661,7 +683,9 @@ __global__ void k_calc_range(const MapDev M, const double* __restrict__ ox, cons
   const int x1 = world_to_cell(ox[i] + mr * ca[i], M.origin_x, M.resolution, M.half_x);
   const int y1 = world_to_cell(oy[i] + mr * sa[i], M.origin_y, M.resolution, M.half_y);
   unsigned long long walked = 0;
-  out[i] = calc_range_skip(M, x0, y0, x1, y1, mr, walked);
+  // (rays of mixed lengths: the integer form where this ray allows it -- both forms return the same cell)
+  out[i] = (fabs(mr) / M.resolution <= (double)kIntDivRayCells) ? calc_range_skip<true>(M, x0, y0, x1, y1, mr, walked)
+                                                                : calc_range_skip<false>(M, x0, y0, x1, y1, mr, walked);
 }
 
 }  // namespace bpf
