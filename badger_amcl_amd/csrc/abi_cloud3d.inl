@@ -42,6 +42,28 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
   e->n_pose_indices = n_pose_indices;
   e->n_ratios = n_distance_ratios;
   e->have_map3d = true;
+  // the dense tiled copy for the scoring kernel's gathers, when a plane fits the 24-bit multiply and the volume 1 GiB
+  M.dense = nullptr;
+  M.dense_k = 0;
+  M.dense_plane = 0;
+  {
+    const long long ntx = (w + 1 + 7) / 8, nty = (h + 1 + 7) / 8;
+    const long long plane = ntx * nty * 64;
+    if (plane < (1 << 24) && 8 * ntx - 1 < (1 << 24) && plane * nz <= (1ll << 30))
+    {
+      HIPCHK(e, e->d_dense3d.reserve((size_t)(plane * nz)));
+      HIPCHK(e, hipMemsetAsync(e->d_dense3d.p, 0xFF, (size_t)(plane * nz), e->stream));
+      const size_t total = (size_t)(w * h * nz);
+      hipLaunchKernelGGL(k_dense3d_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
+                         e->d_pose_indices.p, e->d_ratios.p, (int)w, (int)h, (int)nz, (unsigned)(8 * ntx - 1),
+                         (unsigned)plane, e->d_dense3d.p);
+      HIPCHK(e, hipGetLastError());
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      M.dense = e->d_dense3d.p;
+      M.dense_k = (unsigned)(8 * ntx - 1);
+      M.dense_plane = (unsigned)plane;
+    }
+  }
   return BPF_OK;
 }
 
@@ -321,10 +343,31 @@ int score_cloud(bpf_engine* e, ParticlesDev p, int n, const float* points_xyz, i
     uint64_t bits;
     std::memcpy(&bits, &rinv, 8);
     const bool exact_rinv = (bits & ((1ull << 24) - 1)) == 0 && std::fabs(std::fma(rinv, e->map3.resolution, -1.0)) < 1.1e-16;
-    if (exact_rinv)
-      LAUNCH_TIMED(e, BPF_K_SCORE, k_cloud_score<true>, dim3(n_chunks, A.slabs), dim3(256), 0, A);
+    // scanner mounted without roll or pitch: every particle's matrix has the z row (0, 0, 1) and no z term in x, y
+    // (k_cloud_score, PLANAR); the packed z cell needs 16 bits
+    const bool planar = e->cm.tf_quat[0] == 0.0 && e->cm.tf_quat[1] == 0.0 &&
+                        (e->map3.max_c[2] - e->map3.min_c[2]) < 65534;
+    A.planar_tz = (float)(e->cm.tf_xyz[2] + 0.0);
+    const bool dense = e->map3.dense != nullptr && e->cloud_dense;
+#define BPF_CLOUD_LAUNCH(X, P, D) \
+  LAUNCH_TIMED(e, BPF_K_SCORE, (k_cloud_score<X, P, D>), dim3(n_chunks, A.slabs), dim3(256), 0, A)
+    if (exact_rinv && planar && dense)
+      BPF_CLOUD_LAUNCH(true, true, true);
+    else if (exact_rinv && planar)
+      BPF_CLOUD_LAUNCH(true, true, false);
+    else if (exact_rinv && dense)
+      BPF_CLOUD_LAUNCH(true, false, true);
+    else if (exact_rinv)
+      BPF_CLOUD_LAUNCH(true, false, false);
+    else if (planar && dense)
+      BPF_CLOUD_LAUNCH(false, true, true);
+    else if (planar)
+      BPF_CLOUD_LAUNCH(false, true, false);
+    else if (dense)
+      BPF_CLOUD_LAUNCH(false, false, true);
     else
-      LAUNCH_TIMED(e, BPF_K_SCORE, k_cloud_score<false>, dim3(n_chunks, A.slabs), dim3(256), 0, A);
+      BPF_CLOUD_LAUNCH(false, false, false);
+#undef BPF_CLOUD_LAUNCH
   }
   CloudFinishArgs F{};
   F.p = p;

@@ -669,6 +669,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->graded_shares = value != 0;
   else if (option == BPF_OPT_FUSED_RESAMPLE)
     e->fused_resample = value != 0;
+  else if (option == BPF_OPT_CLOUD_DENSE)
+    e->cloud_dense = value != 0;
   else
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown option");
   return BPF_OK;

@@ -190,7 +190,8 @@ struct bpf_engine
   Map3dDev map3{};
   double map3_max_dist = 0.0;
   DevBuf<uint32_t> d_pose_indices;
-  DevBuf<uint8_t> d_ratios;
+  DevBuf<uint8_t> d_ratios, d_dense3d;
+  bool cloud_dense = true;   // BPF_OPT_CLOUD_DENSE: use the dense tiled volume when there is one
   size_t n_pose_indices = 0, n_ratios = 0;
   bool cloud_configured = false;
   int cloud_max_beams = 0;

@@ -20,10 +20,19 @@
 namespace bpf
 {
 
+// The reference's two-level LUT (pose_indices -> column start in distance_ratios) and, when it fits, the same values
+// as a DENSE volume laid out for the gathers of the scoring kernel: one plane per z cell, inside a plane 8 x 8-cell
+// tiles (64 bytes) with the cells of a tile x-major, cell (i, j, k) of the map at grid position (i + 1, j + 1), so that
+// the byte offset of grid position (x, y) is  8 x + y + (8 ntx - 1) (y & ~7)  (tile row  (y >> 3) ntx 64, tile
+// (x >> 3) 64, inside (x & 7) 8 + (y & 7)).  The 64 lanes of a gather are 64 neighbouring points of the cloud, a
+// short stretch of a wall at one height: a handful of tiles instead of one line per column.
 struct Map3dDev
 {
   const uint32_t* pose_indices;
   const uint8_t* distance_ratios;
+  const uint8_t* dense;        // nullptr: two-level only
+  unsigned dense_k;            // 8 ntx - 1
+  unsigned dense_plane;        // bytes per z plane (< 2^24)
   int min_c[3], max_c[3];
   int width;
   double resolution;
@@ -130,6 +139,20 @@ __device__ __forceinline__ int voxel_rel(float v, double res, double rinv, int m
   return (int)floor(q + 0.5) - min_c;
 }
 
+// The scoring kernel's own form, one step further: cell - min + 1 by TRUNCATION.  With the half folded in and one more
+// added, every on-map coordinate maps to a value >= 1, where truncation and floor agree; everything below the map
+// lands on 0 or a negative number (a huge unsigned), so "on the map" is 1 <= c1 <= span + 1 and the floor is not
+// needed (one instruction per coordinate less).  half_minus_min_plus1 = 1.5 - min.
+__device__ __forceinline__ unsigned voxel1_exact(float v, double rinv, double half_minus_min_plus1)
+{
+  return (unsigned)(int)fma((double)v, rinv, half_minus_min_plus1);
+}
+
+__device__ __forceinline__ unsigned voxel1(float v, double res, double rinv, int min_c)
+{
+  return (unsigned)(voxel_rel(v, res, rinv, min_c) + 1);
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct CloudScoreArgs
@@ -149,13 +172,20 @@ struct CloudScoreArgs
   int round_base[8];
   int round_first_slab[8];
   int n_rounds;
+  float planar_tz;       // PLANAR kernels: the z translation every particle shares, (float)tf_z
 };
 
 #ifdef BPF_PHASE_TIMING
 __device__ unsigned long long g_cloud_span[8192][2];  // diagnostic builds: per-wave start / end (100 MHz clock)
 #endif
 
-template <bool EXACT_RINV>
+// PLANAR: the scanner's mounting has no roll or pitch (tf quaternion x = y = 0).  The particles only add a yaw, so
+// for EVERY particle the float matrix has a[2] = a[5] = a[6] = a[7] = 0 and a[8] = 1 exactly and t2 = (float)tf_z:
+// a point's z voxel does not depend on the particle (wz = pz + t2: the products with 0 and 1 and the sums with 0 are
+// exact) and its x, y are a 2-D rotation (the r2 * pz and r5 * pz terms add an exact zero).  The z voxel, its clamp and
+// its range test are then formed once per chunk at staging and kept in LDS in place of pz.
+// DENSE: one gather from Map3dDev::dense instead of the two-level pair.
+template <bool EXACT_RINV, bool PLANAR, bool DENSE>
 __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
 {
 #pragma clang fp contract(off)
@@ -170,13 +200,37 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
   const int p0 = chunk * kCloudChunk;
   const int np = min(kCloudChunk, A.n_points - p0);
   const int np_pad = (np + 255) & ~255;  // whole groups of 256 points; the padding is finite and contributes zero
+  const Map3dDev& M = A.map;
+  const unsigned span_x = (unsigned)(M.max_c[0] - M.min_c[0]), span_y = (unsigned)(M.max_c[1] - M.min_c[1]),
+                 span_z = (unsigned)(M.max_c[2] - M.min_c[2]);
+  // cells are carried as cell - min + 1 (voxel1): on the map <=> 1 <= c1 <= span + 1
+  const double hm0 = 1.5 - (double)M.min_c[0], hm1 = 1.5 - (double)M.min_c[1], hm2 = 1.5 - (double)M.min_c[2];
   for (int i = threadIdx.x; i < np_pad; i += 256)
   {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
     {
       const float v = (i < np) ? A.points[(size_t)k * A.n_points + p0 + i] : 0.f;
-      s_pts[k][i] = (fabsf(v) <= 3.0e38f) ? v : 1.0e30f;  // NaN / inf: a finite coordinate that is off every map
+      const float f = (fabsf(v) <= 3.0e38f) ? v : 1.0e30f;  // NaN / inf: a finite coordinate that is off every map
+      if (PLANAR && k == 2)
+      {
+        const float wz = f + A.planar_tz;
+        const unsigned c1 = EXACT_RINV ? voxel1_exact(wz, M.inv_resolution, hm2)
+                                       : voxel1(wz, M.resolution, M.inv_resolution, M.min_c[2]);
+        const unsigned cc = min(max(c1, 1u), span_z + 1u);
+        if (DENSE)
+        {
+          // the z plane's byte offset; a point whose z is off the map is off the map for every particle: its x is
+          // replaced by a coordinate that fails the x test, so the loop needs no flag for it
+          s_pts[2][i] = __uint_as_float(cc * M.dense_plane);
+          if (cc != c1)
+            s_pts[0][i] = 1.0e30f;
+        }
+        else  // low half: the clamped z cell (+ 1); high half: 2048 (the table's off-map entry) when z is off the map
+          s_pts[2][i] = __uint_as_float(cc | ((cc != c1) ? (2048u << 16) : 0u));
+      }
+      else
+        s_pts[k][i] = f;
     }
   }
   for (int i = threadIdx.x; i < 258; i += 256)
@@ -184,13 +238,12 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const Map3dDev& M = A.map;
-  const unsigned span_x = (unsigned)(M.max_c[0] - M.min_c[0]), span_y = (unsigned)(M.max_c[1] - M.min_c[1]),
-                 span_z = (unsigned)(M.max_c[2] - M.min_c[2]);
-  const double hm0 = 0.5 - (double)M.min_c[0], hm1 = 0.5 - (double)M.min_c[1], hm2 = 0.5 - (double)M.min_c[2];
   const unsigned width4 = (unsigned)M.width * 4u;
   const char* table_b = reinterpret_cast<const char*>(s_table);
-  const char* pose_b = reinterpret_cast<const char*>(M.pose_indices);
+  // the "+ 1" of the cells is taken back in the base addresses
+  const char* pose_b = reinterpret_cast<const char*>(M.pose_indices) - (size_t)width4 - 4;
+  const uint8_t* ratio_b = M.distance_ratios - 1;
+  const uint8_t* dense_b = M.dense - M.dense_plane;  // plane index = z cell + 1
   const int n_groups = np_pad >> 8;  // wave-uniform: every lane walks the same groups
 
   int j_begin = blockIdx.y * 4 + wave, j_end = A.n, j_step = A.slabs * 4;
@@ -231,15 +284,33 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
     // exec-mask branches, five scalar instructions per evaluation in a kernel that is bound by its instruction
     // count (measured: SQ_ACTIVE_INST_ANY x 4 cycles / SIMD = the kernel's duration).
     auto cell = [&](float wx, float wy, float wz, unsigned& col, unsigned& ck) -> unsigned {
-      const unsigned ci = (unsigned)(EXACT_RINV ? voxel_rel_exact(wx, M.inv_resolution, hm0)
-                                                : voxel_rel(wx, M.resolution, M.inv_resolution, M.min_c[0]));
-      const unsigned cj = (unsigned)(EXACT_RINV ? voxel_rel_exact(wy, M.inv_resolution, hm1)
-                                                : voxel_rel(wy, M.resolution, M.inv_resolution, M.min_c[1]));
-      const unsigned cz = (unsigned)(EXACT_RINV ? voxel_rel_exact(wz, M.inv_resolution, hm2)
-                                                : voxel_rel(wz, M.resolution, M.inv_resolution, M.min_c[2]));
-      const bool ok = ci <= span_x && cj <= span_y && cz <= span_z;
-      col = __umul24(min(cj, span_y), width4) + (min(ci, span_x) << 2);
-      ck = min(cz, span_z);
+      const unsigned ci = EXACT_RINV ? voxel1_exact(wx, M.inv_resolution, hm0)
+                                     : voxel1(wx, M.resolution, M.inv_resolution, M.min_c[0]);
+      const unsigned cj = EXACT_RINV ? voxel1_exact(wy, M.inv_resolution, hm1)
+                                     : voxel1(wy, M.resolution, M.inv_resolution, M.min_c[1]);
+      const unsigned cz = EXACT_RINV ? voxel1_exact(wz, M.inv_resolution, hm2)
+                                     : voxel1(wz, M.resolution, M.inv_resolution, M.min_c[2]);
+      const unsigned xi = min(max(ci, 1u), span_x + 1u), xj = min(max(cj, 1u), span_y + 1u);
+      ck = min(max(cz, 1u), span_z + 1u);
+      const bool ok = xi == ci && xj == cj && ck == cz;
+      if (DENSE)
+        col = __umul24(ck, M.dense_plane) + ((xi << 3) + (__umul24(xj & ~7u, M.dense_k) + xj));
+      else
+        col = __umul24(xj, width4) + (xi << 2);
+      return ok ? 0u : 2048u;
+    };
+    // PLANAR: x and y only; the z cell and its off-map flag come packed from LDS
+    auto cell_xy = [&](float wx, float wy, unsigned& col) -> unsigned {
+      const unsigned ci = EXACT_RINV ? voxel1_exact(wx, M.inv_resolution, hm0)
+                                     : voxel1(wx, M.resolution, M.inv_resolution, M.min_c[0]);
+      const unsigned cj = EXACT_RINV ? voxel1_exact(wy, M.inv_resolution, hm1)
+                                     : voxel1(wy, M.resolution, M.inv_resolution, M.min_c[1]);
+      const unsigned xi = min(max(ci, 1u), span_x + 1u), xj = min(max(cj, 1u), span_y + 1u);
+      const bool ok = xi == ci && xj == cj;
+      if (DENSE)
+        col = (xi << 3) + (__umul24(xj & ~7u, M.dense_k) + xj);
+      else
+        col = __umul24(xj, width4) + (xi << 2);
       return ok ? 0u : 2048u;
     };
     // Two points at a time: the float transform R*p + t with separately rounded products and sums (no contraction),
@@ -259,11 +330,35 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
         const int qa = q0 + 128 * h, qb = qa + 64;
         const f32x2 px = { s_pts[0][qa], s_pts[0][qb] }, py = { s_pts[1][qa], s_pts[1][qb] },
                     pz = { s_pts[2][qa], s_pts[2][qb] };
-        const f32x2 wx = ((r0 * px + r1 * py) + r2 * pz) + t0;
-        const f32x2 wy = ((r3 * px + r4 * py) + r5 * pz) + t1;
-        const f32x2 wz = ((r6 * px + r7 * py) + r8 * pz) + t2;
-        bad[2 * h] = cell(wx.x, wy.x, wz.x, col[2 * h], ck[2 * h]);
-        bad[2 * h + 1] = cell(wx.y, wy.y, wz.y, col[2 * h + 1], ck[2 * h + 1]);
+        if (PLANAR)
+        {
+          const f32x2 wx = (r0 * px + r1 * py) + t0;
+          const f32x2 wy = (r3 * px + r4 * py) + t1;
+          const unsigned za = __float_as_uint(pz.x), zb = __float_as_uint(pz.y);
+          if (DENSE)
+          {
+            bad[2 * h] = cell_xy(wx.x, wy.x, col[2 * h]);
+            bad[2 * h + 1] = cell_xy(wx.y, wy.y, col[2 * h + 1]);
+            col[2 * h] += za;
+            col[2 * h + 1] += zb;
+            ck[2 * h] = ck[2 * h + 1] = 0u;
+          }
+          else
+          {
+            bad[2 * h] = max(cell_xy(wx.x, wy.x, col[2 * h]), za >> 16);
+            bad[2 * h + 1] = max(cell_xy(wx.y, wy.y, col[2 * h + 1]), zb >> 16);
+            ck[2 * h] = za & 0xFFFFu;
+            ck[2 * h + 1] = zb & 0xFFFFu;
+          }
+        }
+        else
+        {
+          const f32x2 wx = ((r0 * px + r1 * py) + r2 * pz) + t0;
+          const f32x2 wy = ((r3 * px + r4 * py) + r5 * pz) + t1;
+          const f32x2 wz = ((r6 * px + r7 * py) + r8 * pz) + t2;
+          bad[2 * h] = cell(wx.x, wy.x, wz.x, col[2 * h], ck[2 * h]);
+          bad[2 * h + 1] = cell(wx.y, wy.y, wz.y, col[2 * h + 1], ck[2 * h + 1]);
+        }
       }
       if (g == n_groups - 1 && np != np_pad)
       {
@@ -274,7 +369,7 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        start[u] = *reinterpret_cast<const uint32_t*>(pose_b + col[u]);
+        start[u] = DENSE ? (unsigned)dense_b[col[u]] : *reinterpret_cast<const uint32_t*>(pose_b + col[u]);
     };
     // Software pipeline over the groups: while the second-level gathers of group g are in flight, the cells and
     // first-level gathers of group g + 1 are formed and issued.
@@ -286,7 +381,7 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
 #pragma unroll
       for (int u = 0; u < U; ++u)
       {
-        lvl[u] = M.distance_ratios[start_c[u] + ck_c[u]];
+        lvl[u] = DENSE ? start_c[u] : (unsigned)ratio_b[start_c[u] + ck_c[u]];
         bad_now[u] = bad_c[u];
       }
       if (g + 1 < n_groups)
@@ -310,6 +405,21 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
     }
   }
 #endif
+}
+
+// the two-level LUT re-laid as the dense tiled volume (Map3dDev); one thread per map cell
+__global__ void k_dense3d_build(const uint32_t* __restrict__ pose_indices, const uint8_t* __restrict__ ratios, int w,
+                                int h, int nz, unsigned dense_k, unsigned plane, uint8_t* __restrict__ dense)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)w * h * nz;
+  if (t >= total)
+    return;
+  const int k = (int)(t % nz);
+  const size_t col = t / nz;
+  const int i = (int)(col % w), j = (int)(col / w);
+  const unsigned x = (unsigned)i + 1u, y = (unsigned)j + 1u;
+  dense[(size_t)k * plane + (x << 3) + y + (size_t)dense_k * (y & ~7u)] = ratios[(size_t)pose_indices[col] + k];
 }
 
 struct CloudFinishArgs

@@ -193,6 +193,9 @@ enum
   BPF_OPT_GRADED_SHARES = 4,  /* default 1: the scoring kernel's waves own particle shares graded by the placement
                                * round of their block; 0 = equal shares.  Results do not
                                * depend on it beyond the summation order of the weight total. */
+  BPF_OPT_CLOUD_DENSE = 6,    /* default 1: the 3-D scoring kernel gathers from a dense tiled copy of the LUT when the
+                               * map allows one (a z plane below 16 MiB, the volume below 1 GiB); 0 = the reference's
+                               * two-level layout.  Same results. */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.

@@ -18,7 +18,7 @@ def engine():
     e.close()
 
 
-def _setup(orc, n, rows, cols, seed=0):
+def _setup(orc, n, rows, cols, seed=0, pitched=False):
     from badger_amcl_amd import synth
     res, max_dist = 0.05, 0.3
     occ = synth.box_room_voxels()
@@ -44,13 +44,20 @@ def _setup(orc, n, rows, cols, seed=0):
     s[:, 2] = yaw + rng.normal(0, 0.05, n)
     s[: n // 10, 0] += 30.0  # some particles off the map
     s[:, 3] = rng.uniform(0.5, 1.5, n) / n
+    if pitched:
+        # a mounting with pitch and roll: the general kernel (the z voxel depends on the particle); yaw-only mountings
+        # take the PLANAR kernels (k_cloud_score)
+        tf_quat = (0.05, 0.07, np.sin(ang / 2), np.cos(ang / 2))
+        nq = np.sqrt(sum(v * v for v in tf_quat))
+        tf_quat = tuple(v / nq for v in tf_quat)
     return lut, pts, s, tf_xyz, tf_quat, max_dist
 
 
+@pytest.mark.parametrize("pitched", [False, True])
 @pytest.mark.parametrize("model", ["plain", "gompertz"])
-def test_cloud_apply_matches_oracle(engine, orc, model):
+def test_cloud_apply_matches_oracle(engine, orc, model, pitched):
     import badger_amcl_amd as bpf
-    lut, pts, s, tf_xyz, tf_quat, max_dist = _setup(orc, 300, 24, 400)
+    lut, pts, s, tf_xyz, tf_quat, max_dist = _setup(orc, 300, 24, 400, pitched=pitched)
     assert pts.shape[0] > 5000  # spans more than one LDS chunk
     om = bpf.OctoMap(engine, 0.05)
     om.setDistancesLUT(lut.pose_indices, lut.distance_ratios, lut.min_cells, lut.max_cells, max_dist)
@@ -78,7 +85,8 @@ def test_cloud_apply_matches_oracle(engine, orc, model):
     assert bad.sum() <= 1, np.flatnonzero(bad)
     assert abs(total - want_total) <= 1e-9 * want_total
     # the scores discriminate: near-truth particles outweigh the displaced ones
-    assert np.median(got[30:, 3] / s[30:, 3]) > np.median(got[:30, 3] / s[:30, 3])
+    if not pitched:
+        assert np.median(got[30:, 3] / s[30:, 3]) > np.median(got[:30, 3] / s[:30, 3])
 
 
 def test_cloud_update_sensor_and_resample(engine, orc):
@@ -120,3 +128,47 @@ def test_cloud_max_beams_below_two(engine, orc):
     got = s.copy()
     assert sc.applyModelToSampleSet(bpf.PointCloudData(pts), got) == 0.0
     assert np.array_equal(got, s)
+
+
+@pytest.mark.parametrize("pitched", [False, True])
+def test_dense_tiled_lut_equals_the_two_level_layout(engine, orc, pitched):
+    """BPF_OPT_CLOUD_DENSE (default on): the scoring kernel gathers from a dense, 8 x 8-tiled copy of the LUT instead
+    of through the reference's two-level layout (octomap.cpp:315-355).  Same voxels, same terms, same summation order:
+    the weights must be bit-identical; with points off every side of the map and non-finite points."""
+    import badger_amcl_amd as bpf
+    import badger_amcl_amd.pf as hpf
+    lut, pts, s, tf_xyz, tf_quat, max_dist = _setup(orc, 700, 24, 400, seed=9, pitched=pitched)
+    pts = pts.copy()
+    pts[::97, 2] += 40.0    # above the map
+    pts[5::89, 2] -= 40.0   # below
+    pts[7::83, 0] += 90.0   # beyond x
+    pts[11::79, 1] -= 90.0  # before y
+    pts[13::211, 0] = np.nan
+    pts[17::223, 2] = np.inf
+    om = bpf.OctoMap(engine, 0.05)
+    om.setDistancesLUT(lut.pose_indices, lut.distance_ratios, lut.min_cells, lut.max_cells, max_dist)
+    sc = bpf.PointCloudScanner(engine)
+    sc.init(128, om)
+    sc.setPointCloudModel(0.5, 0.05, 0.1)
+    sc.setMapFactors(0.95, 0.95, 0.3)
+    sc.setPointCloudScannerToFootprintTF(tf_xyz, tf_quat)
+    data = bpf.PointCloudData(pts)
+    out = {}
+    for mode in (1, 0):
+        engine.set_option(hpf.OPT_CLOUD_DENSE, mode)
+        try:
+            got = s.copy()
+            total = sc.applyModelToSampleSet(data, got)
+            out[mode] = (got[:, 3].copy(), total)
+        finally:
+            engine.set_option(hpf.OPT_CLOUD_DENSE, 1)
+    assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1]
+    # and both equal the oracle (finite points only: the oracle's (int)floor(NaN) is the reference's UB)
+    keep = np.isfinite(pts).all(axis=1)
+    op = orc.cloud(orc.CLOUD_MODEL, 128, tf_xyz, tf_quat, z_hit=0.5, z_rand=0.05, sigma_hit=0.1)
+    op.off_map_factor = 0.95
+    got = s.copy()
+    sc.applyModelToSampleSet(bpf.PointCloudData(pts[keep]), got)
+    want = s.copy()
+    orc.cloud_apply(op, lut, want, pts[keep])
+    assert (rel_err(got[:, 3], want[:, 3]) > 1e-9).sum() <= 1
