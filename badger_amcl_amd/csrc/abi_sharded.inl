@@ -671,6 +671,11 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->fused_resample = value != 0;
   else if (option == BPF_OPT_CLOUD_DENSE)
     e->cloud_dense = value != 0;
+  else if (option == BPF_OPT_STATS_HOST)
+  {
+    e->stats_host = value != 0;
+    e->stats_epoch = -1;
+  }
   else
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "unknown option");
   return BPF_OK;

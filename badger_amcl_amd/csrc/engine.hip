@@ -24,6 +24,7 @@
 #include "kernels_recovery.hpp"
 #include "kernels_pf.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_stats.hpp"
 #include "kernels_score.hpp"
 #include "kernels_window.hpp"
 

@@ -319,6 +319,20 @@ struct bpf_engine
   DevBuf<double> d_gauss, d_init_rot;
   PinnedBuf<long long> h_motion_result;
 
+  // ---- cluster statistics on the device (kernels_stats.hpp)
+  bool stats_host = false;          // BPF_OPT_STATS_HOST: the bit-exact host evaluation instead
+  bool stats_on_device = false;     // the current statistics came from the device
+  bool stats_clusters_fetched = false;
+  int stats_cluster_count = 0, stats_best = -1;
+  double stats_best_weight = 0.0, stats_best_pose[3] = { 0, 0, 0 };
+  DevBuf<int> d_stats_parent, d_stats_label, d_stats_root, d_stats_tiles, d_stats_flags;
+  DevBuf<long long> d_stats_hi;
+  DevBuf<unsigned long long> d_stats_lo;
+  DevBuf<bpf_cluster> d_stats_clusters;
+  DevBuf<StatsResult> d_stats_result;
+  PinnedBuf<StatsResult> h_stats_result;
+  PinnedBuf<int> h_stats_flags;
+
   // ---- cluster statistics (host, lazy)
   std::vector<bpf_cluster> clusters;
   double set_mean[3] = { 0, 0, 0 }, set_cov[5] = { 0, 0, 0, 0, 0 };

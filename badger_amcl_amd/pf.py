@@ -25,6 +25,7 @@ RANDOM_POSE_NONE, RANDOM_POSE_FREE_SPACE_2D = 0, 1
 OPT_CDF_SERIAL, OPT_COUNT_CELLS, OPT_WINDOW_PATH, OPT_KLD_DEVICE_MIN, OPT_GRADED_SHARES = 0, 1, 2, 3, 4
 OPT_FUSED_RESAMPLE = 5
 OPT_CLOUD_DENSE = 6
+OPT_STATS_HOST = 7
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 

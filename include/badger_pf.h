@@ -196,6 +196,9 @@ enum
   BPF_OPT_CLOUD_DENSE = 6,    /* default 1: the 3-D scoring kernel gathers from a dense tiled copy of the LUT when the
                                * map allows one (a z plane below 16 MiB, the volume below 1 GiB); 0 = the reference's
                                * two-level layout.  Same results. */
+  BPF_OPT_STATS_HOST = 7,     /* default 0: cluster statistics on the device (order-independent fixed-point sums: equal to
+                               * the reference's up to summation rounding); 1 = on the host from a copy of the set, in
+                               * the reference's serial order, bit for bit */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.
@@ -262,9 +265,12 @@ int bpf_pf_init_with_random_poses(bpf_engine* e);
 /* ------------------------------------------------------------------ cluster statistics
  * ParticleFilter::computeClusterStatsForSet (particle_filter.cpp:505-636) with PFKDTree::cluster
  * (pf_kdtree.cpp:58-90,169-194), and what Node2D::getMaxWeightPose (node_2d.cpp:588-617) reads.
- * Evaluated on the host, lazily (first query after the set changed), from a copy of the resident
- * set and the engine's histogram tree, in the reference's serial order -- bit-exact, and only a few
- * thousand samples in the tracking regime. */
+ * Evaluated lazily (first query after the set changed) on the device: occupied bins by hash table, clusters by
+ * union-find over the bins' 26-neighbourhoods, labels in the reference's creation order, per-cluster sums as
+ * order-independent 128-bit fixed-point accumulators (equal to the reference's serial sums up to summation rounding,
+ * the same bits every run); the host reads back one small result block, the cluster array only on
+ * bpf_pf_get_cluster.  BPF_OPT_STATS_HOST = 1 evaluates on the host from a copy of the set instead, bit for bit in the
+ * reference's order. */
 typedef struct
 {
   int count;        /* PFCluster::count */

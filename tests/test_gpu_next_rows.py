@@ -24,26 +24,55 @@ def _oracle_stats(orc, samples, max_clusters):
     return t.cluster_stats(samples, max_clusters)
 
 
-def _assert_stats_equal(pf, want):
+def _close(a, b, rtol=1e-12, atol=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+def _assert_stats_equal(pf, want, exact=True, set_atol=1e-12):
+    """exact: the host evaluation (BPF_OPT_STATS_HOST), the reference's serial order bit for bit.  Otherwise the device
+    evaluation: labels, counts and the choice of the heaviest cluster exact; sums differ from the reference's serial
+    double chain by summation rounding only (budget 1e-12, relative for weights and means, absolute for the
+    covariances, which are differences of numbers of order x^2)."""
     n, mean, cov = pf.computeClusterStats()
     assert n == want["n"]
-    assert np.array_equal(mean, want["set_mean"])
-    assert np.array_equal(cov, want["set_cov"], equal_nan=True)
+    if exact:
+        assert np.array_equal(mean, want["set_mean"])
+        assert np.array_equal(cov, want["set_cov"], equal_nan=True)
+    else:
+        assert _close(mean, want["set_mean"], atol=set_atol) and _close(cov, want["set_cov"], atol=max(1e-10, set_atol))
     for k in range(n):
         w, m, cnt, c = pf.getClusterStats(k)
         assert cnt == want["count"][k]
-        assert w == want["weight"][k]
-        assert np.array_equal(m, want["mean"][k])
-        assert np.array_equal(c, want["cov"][k], equal_nan=True)
+        if exact:
+            assert w == want["weight"][k]
+            assert np.array_equal(m, want["mean"][k])
+            assert np.array_equal(c, want["cov"][k], equal_nan=True)
+        else:
+            assert _close(w, want["weight"][k]) and _close(m, want["mean"][k])
+            assert _close(c, want["cov"][k], atol=1e-10)
     assert pf.getClusterStats(n) is None
     best_w, best_pose = pf.getMaxWeightPose()
     if n:
         k = int(np.argmax(want["weight"]))  # first maximum, like the strict '>' scan of node_2d.cpp:608
-        assert best_w == want["weight"][k]
-        assert np.array_equal(best_pose, want["mean"][k])
+        if exact:
+            assert best_w == want["weight"][k]
+            assert np.array_equal(best_pose, want["mean"][k])
+        else:
+            ws = np.sort(want["weight"])[::-1]
+            if ws.size < 2 or ws[0] - ws[1] > 1e-12 * ws[0]:  # (a tie at rounding level may resolve either way)
+                assert _close(best_w, want["weight"][k]) and _close(best_pose, want["mean"][k])
 
 
-def test_cluster_stats_of_loaded_multimodal_set(engine, orc):
+@pytest.fixture(params=["device", "host"])
+def stats_mode(request, engine):
+    import badger_amcl_amd.pf as hpf
+    engine.set_option(hpf.OPT_STATS_HOST, 1 if request.param == "host" else 0)
+    yield request.param == "host"
+    engine.set_option(hpf.OPT_STATS_HOST, 0)
+
+
+def test_cluster_stats_of_loaded_multimodal_set(engine, orc, stats_mode):
     """Three separated blobs + stragglers: several clusters, bit-exact counts / weights / means / covs."""
     sc_ = Scenario(orc, size=400, n=3000, beams=61, cloud="converged")
     pose = sc_.pose
@@ -56,13 +85,13 @@ def test_cluster_stats_of_loaded_multimodal_set(engine, orc):
     m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf", min_samples=100, seed=3)
     want = _oracle_stats(orc, s, s.shape[0])
     assert want["n"] >= 3
-    _assert_stats_equal(pf, want)
+    _assert_stats_equal(pf, want, stats_mode)
     # cached: a second query without a change of the set gives the same answer
-    _assert_stats_equal(pf, want)
+    _assert_stats_equal(pf, want, stats_mode)
 
 
 @pytest.mark.parametrize("resampler", [0, 1])
-def test_cluster_stats_after_update_and_resample(engine, orc, resampler):
+def test_cluster_stats_after_update_and_resample(engine, orc, resampler, stats_mode):
     """The statistics the node reads after updateResample (particle_filter.cpp:464-468): the engine's
     histogram tree of the resampled set is reused for the labelling."""
     sc_ = Scenario(orc, size=400, n=4000, beams=91, cloud="mixture")
@@ -71,16 +100,58 @@ def test_cluster_stats_after_update_and_resample(engine, orc, resampler):
     sc.updateSensor(pf, data)
     # weighted, not yet resampled: tree from initWithSamples
     cur = pf.getCurrentSet().samples
-    _assert_stats_equal(pf, _oracle_stats(orc, cur, 4000))
+    _assert_stats_equal(pf, _oracle_stats(orc, cur, 4000), stats_mode)
     pf.updateResample()
     cur = pf.getCurrentSet().samples
-    _assert_stats_equal(pf, _oracle_stats(orc, cur, 4000))
+    _assert_stats_equal(pf, _oracle_stats(orc, cur, 4000), stats_mode)
     # restore() invalidates the tree; the statistics rebuild it from the set
     pf.snapshot()
     sc.updateSensor(pf, data)
     pf.updateResample()
     pf.restore()
-    _assert_stats_equal(pf, _oracle_stats(orc, cur, 4000))
+    _assert_stats_equal(pf, _oracle_stats(orc, cur, 4000), stats_mode)
+
+
+def test_cluster_stats_on_device_full_size_spread_set(engine, orc):
+    """100 000 spread particles after scoring and resampling (no early stop: M = 100 000, thousands
+    of clusters): the device evaluation against the oracle's serial one -- cluster count, every cluster's label (via
+    its count), weights / means / covariances within the rounding budget, the heaviest cluster -- without a copy of
+    the set to the host (bpf_pf_get_max_weight_pose reads one result block).  Two runs give the same bits."""
+    sc_ = Scenario(orc, size=2000, n=100000, beams=181, cloud="spread")
+    m, sc, pf, data = sc_.gpu_objects(engine, 181, "lf", min_samples=100, seed=21)
+    sc.updateSensor(pf, data)
+    cur = pf.getCurrentSet().samples
+    want = _oracle_stats(orc, cur, 100000)
+    assert want["n"] > 500
+    # set-level sums run over all 100 000 samples: the reference's serial double chain itself carries up to n eps of
+    # rounding there (1e-8 absolute on a covariance of 800 m^2; the device sum is exact, checked against math.fsum
+    # below), and the circular mean of uniformly spread headings divides it by a resultant of ~1e-3 -- hence the
+    # wider budget against the ORACLE for the set's own mean / covariance
+    _assert_stats_equal(pf, want, exact=False, set_atol=1e-7)
+    # ... and the device's set statistics ARE the exactly summed ones: against math.fsum of the same double terms
+    import math
+    w, x, y = cur[:, 3], cur[:, 0], cur[:, 1]
+    W = math.fsum(w)
+    mx, my = math.fsum(w * x) / W, math.fsum(w * y) / W
+    exact_cov = [math.fsum(w * x * x) / W - mx * mx, math.fsum(w * x * y) / W - mx * my,
+                 math.fsum(w * y * x) / W - my * mx, math.fsum(w * y * y) / W - my * my]
+    _, mean_d, cov_d = pf.computeClusterStats()
+    assert abs(mean_d[0] - mx) <= 1e-13 * abs(mx) and abs(mean_d[1] - my) <= 1e-13 * abs(my)
+    assert np.allclose(cov_d[:4], exact_cov, rtol=0, atol=1e-11)
+    first = pf.getMaxWeightPose(), pf.computeClusterStats()
+    pf.updateResample()
+    assert pf.getState().sample_count == 100000
+    cur = pf.getCurrentSet().samples
+    want = _oracle_stats(orc, cur, 100000)
+    _assert_stats_equal(pf, want, exact=False, set_atol=1e-7)
+    # order-independent accumulation: the same bits when evaluated again from scratch
+    pf.snapshot()
+    pf.restore()
+    again_w, again_pose = pf.getMaxWeightPose()
+    n2, mean2, cov2 = pf.computeClusterStats()
+    n1, mean1, cov1 = pf.computeClusterStats()
+    assert n1 == n2 and np.array_equal(mean1, mean2) and np.array_equal(cov1, cov2)
+    assert first[1][0] > 0 and again_w > 0
 
 
 def test_reference_brushfire_lut_is_bit_identical(engine, orc):

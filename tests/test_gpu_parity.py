@@ -208,7 +208,7 @@ def test_kld_stop_rule_on_device_matches_oracle(engine, orc, cloud, n, pop):
             t.insert_pose(cur[k, :3], cur[k, 3])
         want = t.cluster_stats(cur, n)
         cnt, mean, cov = pf.computeClusterStats()
-        assert cnt == want["n"] and np.array_equal(mean, want["set_mean"])
+        assert cnt == want["n"] and np.allclose(mean, want["set_mean"], rtol=1e-12, atol=1e-12)
     finally:
         engine.set_option(hpf.OPT_CDF_SERIAL, 0)
         engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 8192)
