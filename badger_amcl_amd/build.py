@@ -7,6 +7,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "engine.hip")
 OUT = os.path.join(HERE, "libbadger_pf_hip.so")
+# the RCCL collectives of the sharded path: a separate object linked against librccl (570 MB), loaded by
+# bpf_shard_bootstrap only on ranks that cannot use the mailbox exchange
+SRC_RCCL = os.path.join(HERE, "csrc", "collectives_rccl.cpp")
+OUT_RCCL = os.path.join(HERE, "libbadger_pf_rccl.so")
 
 
 def deps():
@@ -30,7 +34,20 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps())
 
 
+def build_rccl(force=False, verbose=False):
+    if not force and os.path.exists(OUT_RCCL) and os.path.getmtime(OUT_RCCL) >= os.path.getmtime(SRC_RCCL):
+        return OUT_RCCL
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(hipcc())), "lib")
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-o", OUT_RCCL, SRC_RCCL, "-L", rocm_lib, "-lrccl",
+           "-Wl,-rpath," + rocm_lib]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return OUT_RCCL
+
+
 def build(force=False, verbose=False):
+    build_rccl(force, verbose)
     if not force and not needs_build():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]

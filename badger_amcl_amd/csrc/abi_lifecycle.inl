@@ -40,6 +40,7 @@ void bpf_destroy(bpf_engine* e)
     if (s.done)
       (void)hipEventDestroy(s.done);
   }
+  collective_release(e);
   mailbox_release(e);
   if (e->targets_read)
     (void)hipEventDestroy(e->targets_read);

@@ -46,6 +46,8 @@ int bpf_shard_mailbox_create(bpf_engine* e, int rank, int world, long long max_w
   m.rank = rank;
   m.world = world;
   m.max_window = max_window;
+  e->shard_rank = rank;
+  e->shard_world = world;
   HIPCHK(e, e->h_mb_error.reserve(1));
   e->h_mb_error.p[0] = 0;
   HIPCHK(e, e->h_mb_result.reserve(1));

@@ -2,14 +2,67 @@
 // kernels there is nothing left for a host-side collective layer to do between the stage functions, so the whole
 // sequence of badger_amcl_amd/sharded.py runs here, stage function by stage function (same order, same arguments),
 // and the host pays one call per update instead of a dozen.
+//
+// The same sequence also runs with RCCL collectives between the stages (bpf_shard_bootstrap falls back to that when the
+// mailbox cannot be set up): the totals go through ncclAllGather after the scoring stage and every draw window through
+// an integer ncclAllReduce(sum) before its first consumer -- ShardExchange hides which of the two it is.
 namespace
 {
-long long* mailbox_next_window(bpf_engine* e, int* stride)
+struct ShardExchange
 {
-  void* w = nullptr;
-  if (bpf_shard_mailbox_window(e, &w, stride) != BPF_OK)
-    return nullptr;
-  return static_cast<long long*>(w);
+  bpf_engine* e;
+  bool collective() const { return !e->mb.active; }
+
+  // a fresh [6][stride] int64 window for `count` draws
+  long long* next_window(int count, int* stride)
+  {
+    if (!collective())
+    {
+      void* w = nullptr;
+      if (bpf_shard_mailbox_window(e, &w, stride) != BPF_OK)
+        return nullptr;
+      return static_cast<long long*>(w);
+    }
+    // two buffers in turn: the previous window stays readable while the next one is assembled
+    DevBuf<long long>& buf = e->coll.window[e->coll.window_turn ^= 1];
+    const size_t cols = (size_t)((count + 255) / 256) * 256;
+    if (buf.reserve(6 * cols) != hipSuccess)
+    {
+      e->fail(BPF_ERR_HIP, "collective window allocation");
+      return nullptr;
+    }
+    *stride = (int)cols;
+    return buf.p;
+  }
+
+  // every shard's columns into every shard's copy of the window
+  int assemble(long long* window, int stride)
+  {
+    if (!collective())
+      return BPF_OK;  // the draw kernel stored them into all peers; the window's first consumer waits for them
+    if (e->coll.fn.allreduce_sum_i64(e->coll.comm, window, (size_t)6 * stride, e->stream) != 0)
+      return e->fail(BPF_ERR_EXCHANGE, std::string("RCCL window all-reduce: ") + e->coll.fn.last_error());
+    return BPF_OK;
+  }
+
+  // the W weight totals of the scoring stage just issued
+  int totals(void** out)
+  {
+    if (!collective())
+      return bpf_shard_mailbox_totals(e, out);
+    HIPCHK(e, e->coll.totals.reserve((size_t)e->shard_world));
+    if (e->coll.fn.allgather_f64(e->coll.comm, &e->d_scalars.p->v[0], e->coll.totals.p, 1, e->stream) != 0)
+      return e->fail(BPF_ERR_EXCHANGE, std::string("RCCL totals all-gather: ") + e->coll.fn.last_error());
+    *out = e->coll.totals.p;
+    return BPF_OK;
+  }
+};
+
+int shard_step_ready(bpf_engine* e)
+{
+  if (!e->mb.active && !e->coll.active)
+    return e->fail(BPF_ERR_NOT_CONFIGURED, "no shard exchange set up (bpf_shard_bootstrap / bpf_shard_mailbox_connect)");
+  return BPF_OK;
 }
 }  // namespace
 
@@ -18,19 +71,33 @@ int bpf_shard_mailbox_update_sensor_planar(bpf_engine* e, const double* ranges, 
 {
   if (!e || global_count <= 0)
     return BPF_ERR_INVALID_ARGUMENT;
-  if (!e->mb.active)
-    return e->fail(BPF_ERR_NOT_CONFIGURED, "mailbox not connected");
-  e->mb_totals_valid = false;
-  int rc = bpf_shard_score_planar(e, ranges, angles, range_count, range_max);
+  int rc = shard_step_ready(e);
   if (rc != BPF_OK)
-    return rc;  // includes BPF_SHARD_NEED_BEAM_COUNTS: beam skipping needs the caller's all-reduce in between
+    return rc;
+  ShardExchange X{ e };
+  e->mb_totals_valid = false;
+  rc = bpf_shard_score_planar(e, ranges, angles, range_count, range_max);
+  if (rc == BPF_SHARD_NEED_BEAM_COUNTS && X.collective())
+  {
+    // beam skipping: the per-beam agreement counts are summed over the shards between the two passes
+    void* counts = nullptr;
+    int n_counts = 0;
+    rc = bpf_shard_beam_counts_dev(e, &counts, &n_counts);
+    if (rc != BPF_OK)
+      return rc;
+    if (e->coll.fn.allreduce_sum_i32(e->coll.comm, static_cast<int*>(counts), (size_t)n_counts, e->stream) != 0)
+      return e->fail(BPF_ERR_EXCHANGE, std::string("RCCL beam-count all-reduce: ") + e->coll.fn.last_error());
+    rc = bpf_shard_score_planar_finish(e, ranges, angles, range_count, range_max, global_count);
+  }
+  if (rc != BPF_OK)
+    return rc;  // includes BPF_SHARD_NEED_BEAM_COUNTS (mailbox mode): the caller sums the counts in between
   if (e->pm.max_beams < 2)
     return BPF_OK;
   void* totals = nullptr;
-  rc = bpf_shard_mailbox_totals(e, &totals);
+  rc = X.totals(&totals);
   if (rc != BPF_OK)
     return rc;
-  rc = bpf_shard_normalize_dev(e, totals, e->mb.world, (int)global_count);
+  rc = bpf_shard_normalize_dev(e, totals, e->shard_world, (int)global_count);
   if (rc != BPF_OK)
     return rc;
   e->mb_totals = totals;
@@ -45,15 +112,19 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
     return BPF_ERR_INVALID_ARGUMENT;
   if (!e->have_pf)
     return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
-  if (!e->mb.active || !e->mb_totals_valid)
+  int rc = shard_step_ready(e);
+  if (rc != BPF_OK)
+    return rc;
+  if (!e->mb_totals_valid)
     return e->fail(BPF_ERR_NOT_CONFIGURED,
-                   "mailbox resample: needs the totals of bpf_shard_mailbox_update_sensor_planar of this update");
+                   "sharded resample: needs the totals of bpf_shard_mailbox_update_sensor_planar of this update");
   HIPCHK(e, hipSetDevice(e->device));
-  const int rank = e->mb.rank, W = e->mb.world;
+  ShardExchange X{ e };
+  const int rank = e->shard_rank, W = e->shard_world;
   const int max_global = e->max_samples;  // engines of a sharded filter carry the GLOBAL bounds
-  if (max_global > e->mb.max_window)
+  if (!X.collective() && max_global > e->mb.max_window)
     return e->fail(BPF_ERR_CAPACITY, "mailbox windows are smaller than max_samples");
-  int rc = bpf_shard_build_cdf(e, flags_dev);
+  rc = bpf_shard_build_cdf(e, flags_dev);
   if (rc != BPF_OK)
     return rc;
   const uint64_t rng = e->rng;
@@ -77,10 +148,13 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
   };
   if (e->resample_model == BPF_RESAMPLE_SYSTEMATIC)
   {
-    long long* window = mailbox_next_window(e, &stride);
+    long long* window = X.next_window(sys_count, &stride);
     if (!window)
       return e->last_status;
     rc = bpf_shard_systematic_window_dev(e, rng, sys_count, e->mb_totals, 1, rank, W, window, stride, flags_dev);
+    if (rc != BPF_OK)
+      return rc;
+    rc = X.assemble(window, stride);
     if (rc != BPF_OK)
       return rc;
     bpf_kld_reset(e);
@@ -113,10 +187,13 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
       {
         // no stop so far and a long stream ahead (a spread cloud): one window with every candidate, and the ordered
         // kd-tree replay runs on the device (every rank, redundantly)
-        long long* whole = mailbox_next_window(e, &stride);
+        long long* whole = X.next_window(max_global, &stride);
         if (!whole)
           return e->last_status;
         rc = bpf_shard_draw_window_dev(e, rng, 0, max_global, e->mb_totals, 1, rank, W, whole, stride, flags_dev);
+        if (rc != BPF_OK)
+          return rc;
+        rc = X.assemble(whole, stride);
         if (rc != BPF_OK)
           return rc;
         int handled = 0, dstop = -1, dleaf = 0, dbins = 0;
@@ -139,10 +216,13 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
         device_declined = true;  // this stream is outside what the device tree takes: host replay
       }
       const int m1 = std::min(max_global, m0 + win), cnt = m1 - m0;
-      long long* window = mailbox_next_window(e, &stride);
+      long long* window = X.next_window(cnt, &stride);
       if (!window)
         return e->last_status;
       rc = bpf_shard_draw_window_dev(e, rng, m0, m1, e->mb_totals, 1, rank, W, window, stride, flags_dev);
+      if (rc != BPF_OK)
+        return rc;
+      rc = X.assemble(window, stride);
       if (rc != BPF_OK)
         return rc;
       rc = bpf_kld_feed_dev(e, window, stride, cnt, m0, &stop);  // the one host wait of the window

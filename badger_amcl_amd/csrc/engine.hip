@@ -43,7 +43,8 @@ namespace
 extern "C" {
 namespace
 {
-void mailbox_release(bpf_engine* e);  // abi_mailbox.inl
+void mailbox_release(bpf_engine* e);     // abi_mailbox.inl
+void collective_release(bpf_engine* e);  // abi_bootstrap.inl
 }
 #include "abi_lifecycle.inl"
 #include "abi_map2d.inl"
@@ -57,5 +58,6 @@ void mailbox_release(bpf_engine* e);  // abi_mailbox.inl
 #include "abi_mailbox.inl"
 #include "abi_sharded.inl"
 #include "abi_mailbox_step.inl"
+#include "abi_bootstrap.inl"
 #include "abi_measure.inl"
 }  // extern "C"

@@ -292,6 +292,29 @@ struct bpf_engine
     unsigned long long hello = 0;
     int fold_deferred = 0;          // > 0: that many scoring partials wait to be folded and posted by the normalise launch
   } mb;
+  int shard_rank = 0, shard_world = 1;  // of the shard exchange in use (mailbox or collective)
+  // ---- RCCL collectives (libbadger_pf_rccl.so, loaded by bpf_shard_bootstrap when the mailbox cannot be used)
+  struct Collective
+  {
+    bool active = false;
+    void* lib = nullptr;
+    void* comm = nullptr;
+    struct Fn
+    {
+      const char* (*last_error)() = nullptr;
+      int (*unique_id_bytes)() = nullptr;
+      int (*unique_id)(void*) = nullptr;
+      int (*init)(void**, int, int, const void*) = nullptr;
+      int (*destroy)(void*) = nullptr;
+      int (*allgather_f64)(void*, const double*, double*, size_t, void*) = nullptr;
+      int (*allreduce_sum_i64)(void*, long long*, size_t, void*) = nullptr;
+      int (*allreduce_sum_i32)(void*, int*, size_t, void*) = nullptr;
+    } fn;
+    DevBuf<double> totals;
+    DevBuf<long long> window[2];
+    int window_turn = 0;
+  } coll;
+  DevBuf<int> d_shard_flags;        // the CDF-miss flag word of the one-call sharded updates
   void* mb_totals = nullptr;        // bpf_shard_mailbox_update_sensor_planar: this update's totals (mailbox slots)
   bool mb_totals_valid = false;
   DevBuf<double> d_shard_out;       // [3][max_samples] poses of a resample that spans several windows

@@ -449,6 +449,35 @@ int bpf_shard_mailbox_selftest(bpf_engine* e, int rounds);
 int bpf_shard_mailbox_destroy(bpf_engine* e);
 int bpf_shard_mailbox_totals(bpf_engine* e, void** totals_dev);
 int bpf_shard_mailbox_window(bpf_engine* e, void** window_dev, int* stride);
+/* Bring-up of a sharded filter from a plain C / C++ host (no Python, no MPI, no launcher): every rank of the node calls
+ * bpf_shard_bootstrap with the same "host:port".  Rank 0 listens there, the others connect (TCP inside this library);
+ * over those sockets the ranks gather the mailbox IPC handles, map each other's mailboxes, run the connect round and the
+ * self-test and agree on the result.  When the mailbox cannot be used on every rank they all fall back to RCCL:
+ * libbadger_pf_rccl.so (linked against librccl, loaded only then) joins a communicator whose unique id rank 0 hands out
+ * over the same sockets, and the two exchanges become ncclAllGather (totals) and an integer ncclAllReduce (windows).
+ * *mode_out: which one it is.  flags: BPF_BOOTSTRAP_FORCE_COLLECTIVE skips the mailbox, BPF_BOOTSTRAP_MAILBOX_ONLY
+ * fails instead of falling back.  The sockets are closed before the call returns.  The engine must carry the GLOBAL
+ * min / max sample counts (bpf_pf_create) and this rank's shard of the set. */
+enum
+{
+  BPF_SHARD_EXCHANGE_MAILBOX = 1,
+  BPF_SHARD_EXCHANGE_RCCL = 2
+};
+enum
+{
+  BPF_BOOTSTRAP_FORCE_COLLECTIVE = 1,
+  BPF_BOOTSTRAP_MAILBOX_ONLY = 2
+};
+int bpf_shard_bootstrap(bpf_engine* e, int rank, int world, const char* host_port, long long max_window, int flags,
+                        int* mode_out);
+int bpf_shard_shutdown(bpf_engine* e);
+/* The sharded sensor update and resample as one call each, over whichever exchange bpf_shard_bootstrap (or
+ * bpf_shard_mailbox_connect) set up; arguments as bpf_shard_mailbox_update_sensor_planar / _update_resample, with the
+ * CDF-miss flag word owned by the engine (*cdf_miss_out, nullable, reads it back). */
+int bpf_shard_update_sensor_planar(bpf_engine* e, const double* ranges, const double* angles, int range_count,
+                                   double range_max, long long global_count);
+int bpf_shard_update_resample(bpf_engine* e, int* global_count_io, int* leaf_count_io, int* bin_count_out,
+                              int* windows_out, int* window_hint_io, int* cdf_miss_out);
 /* insert every key of the window into the engine's histogram tree (no stop rule): the tree of a systematic
  * resample, or of an initial set (keys as bpf_kld_feed / bpf_kld_feed_dev take them) */
 int bpf_kld_insert(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys);
