@@ -48,8 +48,10 @@ int bpf_shard_mailbox_create(bpf_engine* e, int rank, int world, long long max_w
   m.max_window = max_window;
   e->shard_rank = rank;
   e->shard_world = world;
-  HIPCHK(e, e->h_mb_error.reserve(1));
-  e->h_mb_error.p[0] = 0;
+  HIPCHK(e, e->h_mb_error.reserve(2));
+  e->h_mb_error.p[0] = e->h_mb_error.p[1] = 0;
+  HIPCHK(e, e->d_mb_error.reserve(2));
+  HIPCHK(e, hipMemsetAsync(e->d_mb_error.p, 0, 2 * sizeof(unsigned), e->stream));
   HIPCHK(e, e->h_mb_result.reserve(1));
   HIPCHK(e, e->d_mb_counter.reserve(1));
   HIPCHK(e, hipMemsetAsync(e->d_mb_counter.p, 0, sizeof(unsigned), e->stream));
@@ -69,6 +71,8 @@ MailboxDev mailbox_dev(const bpf_engine* e)
   for (int r = 0; r < e->mb.world; ++r)
     M.peer[r] = e->mb.peer[r];
   M.host_error = e->h_mb_error.p;
+  M.dev_error = e->d_mb_error.p;
+  M.timeout_ticks = (long long)e->mb_timeout_ms * 100000ll;
   return M;
 }
 
@@ -81,7 +85,7 @@ int mailbox_hello(bpf_engine* e)
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipStreamSynchronize(e->stream));
   if (e->h_mb_result.p[0] != 1)
-    return e->fail(BPF_ERR_EXCHANGE, "mailbox: a peer's word did not arrive within 5 s");
+    return e->fail(BPF_ERR_EXCHANGE, "mailbox: a peer's word did not arrive in time");
   return BPF_OK;
 }
 
@@ -93,11 +97,37 @@ bool mailbox_owns(const bpf_engine* e, const void* p)
 
 int mailbox_check(bpf_engine* e)
 {
-  if (e->mb.active && __atomic_load_n(e->h_mb_error.p, __ATOMIC_ACQUIRE) != 0)
-    return e->fail(BPF_ERR_EXCHANGE, "mailbox: a wait for a peer ran out of time (5 s); the shards are out of step");
+  if (e->mb.active && (__atomic_load_n(e->h_mb_error.p, __ATOMIC_ACQUIRE) != 0 ||
+                       __atomic_load_n(e->h_mb_error.p + 1, __ATOMIC_ACQUIRE) != 0))
+    return e->fail(BPF_ERR_EXCHANGE, "mailbox: a wait for a peer ran out of time; the shards are out of step "
+                                     "(bpf_shard_mailbox_error_stage tells which exchange)");
   return BPF_OK;
 }
 }  // namespace
+
+int bpf_shard_mailbox_set_timeout_ms(bpf_engine* e, int timeout_ms)
+{
+  if (!e || timeout_ms < 1 || timeout_ms > 600000)
+    return BPF_ERR_INVALID_ARGUMENT;
+  e->mb_timeout_ms = timeout_ms;
+  return BPF_OK;
+}
+
+int bpf_shard_mailbox_error_stage(bpf_engine* e, int* totals_failed, int* window_failed)
+{
+  if (!e || !totals_failed || !window_failed)
+    return BPF_ERR_INVALID_ARGUMENT;
+  *totals_failed = *window_failed = 0;
+  if (e->h_mb_error.p)
+  {
+    // the flags are raised by kernels: let the stream drain so that a wait still spinning has decided
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    *totals_failed = __atomic_load_n(e->h_mb_error.p, __ATOMIC_ACQUIRE) != 0;
+    *window_failed = __atomic_load_n(e->h_mb_error.p + 1, __ATOMIC_ACQUIRE) != 0;
+  }
+  return BPF_OK;
+}
 
 int bpf_shard_mailbox_connect(bpf_engine* e, const void* handles)
 {

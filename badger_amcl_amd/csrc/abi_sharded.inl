@@ -174,7 +174,8 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
   hipLaunchKernelGGL(k_normalize_gathered, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
                      static_cast<const double*>(totals_dev), world, global_sample_count, e->d_scalars.p,
                      e->alpha_slow, e->alpha_fast, e->d_tile_sums.p, wait, (int)(e->mb.tot_gen & 1),
-                     e->mb.tot_gen, fold, n_fold);
+                     e->mb.tot_gen, fold, n_fold,
+                     (mailbox_owns(e, totals_dev) && e->d_mb_error.p) ? (const unsigned*)e->d_mb_error.p : nullptr);
   HIPCHK(e, hipGetLastError());
   e->tile_sums_n = n;
   return BPF_OK;

@@ -319,6 +319,8 @@ struct bpf_engine
   bool mb_totals_valid = false;
   DevBuf<double> d_shard_out;       // [3][max_samples] poses of a resample that spans several windows
   PinnedBuf<unsigned> h_mb_error;
+  DevBuf<unsigned> d_mb_error;
+  int mb_timeout_ms = 5000;
   PinnedBuf<int> h_mb_result;
   DevBuf<unsigned> d_mb_counter;
 

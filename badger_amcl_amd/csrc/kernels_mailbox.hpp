@@ -26,7 +26,7 @@ namespace bpf
 
 constexpr int kMailboxMaxWorld = 16;
 constexpr size_t kMailboxHeader = 4096;
-constexpr long long kMailboxTimeoutTicks = 500000000ll;  // 5 s of the 100 MHz wall clock
+constexpr long long kMailboxTimeoutTicks = 500000000ll;  // default: 5 s of the 100 MHz wall clock
 constexpr int kMailboxFusedWaitBlocks = 64;               // consumers with more blocks get k_mailbox_wait in front
 
 struct MailboxDev
@@ -34,7 +34,9 @@ struct MailboxDev
   int rank, world;                // world == 0: no mailbox (the kernels skip their post / wait)
   long long max_window;           // columns per window row
   char* peer[kMailboxMaxWorld];   // every rank's mailbox as mapped into this process (own included)
-  unsigned* host_error;           // pinned host word: set to 1 by a wait that ran out of time
+  unsigned* host_error;           // pinned host words, set to 1 by a wait that ran out of time: [0] totals, [1] window
+  unsigned* dev_error;            // the same two flags in device memory, for the kernels behind a k_mailbox_wait
+  long long timeout_ticks;        // bound of a wait (100 MHz wall clock)
 };
 
 __device__ __forceinline__ unsigned long long* mb_tot_gen(char* base, int parity, int r)
@@ -53,35 +55,62 @@ __device__ __forceinline__ unsigned long long* mb_hello(char* base, int r)
 {
   return reinterpret_cast<unsigned long long*>(base + 768) + r;
 }
+// "rank r gave up a wait": set by r in every peer's mailbox when one of its waits runs out, and looked at by every
+// wait of every rank (even one whose words are all there), so that a rank that stalled finds out that its peer has
+// stopped waiting for it and does not finish the step alone
+__device__ __forceinline__ unsigned long long* mb_fail(char* base, int r)
+{
+  return reinterpret_cast<unsigned long long*>(base + 1024) + r;
+}
 __device__ __forceinline__ long long* mb_window(char* base, int parity, long long max_window)
 {
   return reinterpret_cast<long long*>(base + kMailboxHeader) + (size_t)parity * 6 * (size_t)max_window;
 }
 
-// bounded spin until *slot >= gen; false when the 5 s ran out (every wave reaches the exit either way)
-__device__ __forceinline__ bool mb_spin_ge(const unsigned long long* slot, unsigned long long gen)
+// bounded spin until *slot >= gen; false when the time ran out (every wave reaches the exit either way)
+__device__ __forceinline__ bool mb_spin_ge(const unsigned long long* slot, unsigned long long gen, long long timeout_ticks)
 {
   const long long t0 = wall_clock64();
   for (;;)
   {
     if (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= gen)
       return true;
-    if (wall_clock64() - t0 > kMailboxTimeoutTicks)
+    if (wall_clock64() - t0 > timeout_ticks)
       return false;
     __builtin_amdgcn_s_sleep(2);
   }
 }
 
 // Block-wide wait on `world` generation words of this rank's own mailbox (threads 0 .. world-1 spin, the
-// rest wait at the barrier); every thread of the block must call it.
-__device__ __forceinline__ void mb_block_wait(const MailboxDev& M, unsigned long long* first_slot,
-                                              unsigned long long gen)
+// rest wait at the barrier); every thread of the block must call it.  which: 0 = totals, 1 = window.  False (for the
+// whole block) when a word did not arrive in time: the flags are raised and the caller must leave its data alone, so
+// that the host can finish the update over another transport (ShardedFilter's recovery).  A rank that gives up says so
+// in every peer's mailbox, and every wait also fails when a peer has said so: the rank whose stall caused the
+// time-out finds its words all there (its peer posted them long ago) but must not finish the step alone.
+__device__ __forceinline__ bool mb_block_wait(const MailboxDev& M, unsigned long long* first_slot,
+                                              unsigned long long gen, int which)
 {
+  int ok = 1;
   if ((int)threadIdx.x < M.world)
-    if (!mb_spin_ge(first_slot + threadIdx.x, gen))
-      __hip_atomic_store(M.host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __syncthreads();
+  {
+    if (!mb_spin_ge(first_slot + threadIdx.x, gen, M.timeout_ticks))
+      ok = 0;
+    // a peer that has given up a wait of its own no longer takes part in this step
+    if (__hip_atomic_load(mb_fail(M.peer[M.rank], threadIdx.x), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull)
+      ok = 0;
+  }
+  ok = __syncthreads_and(ok);
+  if (!ok && (int)threadIdx.x < M.world)
+  {
+    __hip_atomic_store(mb_fail(M.peer[threadIdx.x], M.rank), 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0)
+    {
+      __hip_atomic_store(M.host_error + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(M.dev_error + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // what the peers wrote before their words is visible to every thread
+  return ok != 0;
 }
 
 // thread t < world stores this rank's total into peer t's mailbox, then the generation word
@@ -125,7 +154,8 @@ __global__ void k_mailbox_post_total(const double* value, const MailboxDev M, in
 // kernel they are waiting for from being scheduled).  which: 0 = totals words, 1 = window "done" words.
 __global__ void k_mailbox_wait(const MailboxDev M, int which, int parity, unsigned long long gen)
 {
-  mb_block_wait(M, which == 0 ? mb_tot_gen(M.peer[M.rank], parity, 0) : mb_win_done(M.peer[M.rank], parity, 0), gen);
+  (void)mb_block_wait(M, which == 0 ? mb_tot_gen(M.peer[M.rank], parity, 0) : mb_win_done(M.peer[M.rank], parity, 0), gen,
+                      which);
 }
 
 // Self-test of the window path with a payload that can be checked: rank r stores pattern(r, gen, column) into the
@@ -155,7 +185,7 @@ __global__ void k_mailbox_selftest_write(const MailboxDev M, int n_cols, int par
 __global__ void k_mailbox_selftest_check(const MailboxDev M, int n_cols, int parity, unsigned long long gen,
                                          int* mismatches)
 {
-  mb_block_wait(M, mb_win_done(M.peer[M.rank], parity, 0), gen);
+  (void)mb_block_wait(M, mb_win_done(M.peer[M.rank], parity, 0), gen, 1);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cols)
     return;
@@ -178,7 +208,7 @@ __global__ void k_mailbox_hello(const MailboxDev M, unsigned long long token, in
   if ((int)threadIdx.x < M.world)
   {
     __hip_atomic_store(mb_hello(M.peer[threadIdx.x], M.rank), token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!mb_spin_ge(mb_hello(M.peer[M.rank], threadIdx.x), token))
+    if (!mb_spin_ge(mb_hello(M.peer[M.rank], threadIdx.x), token, M.timeout_ticks))
       atomicExch(&s_ok, 0);
   }
   __syncthreads();

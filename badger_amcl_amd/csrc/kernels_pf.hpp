@@ -351,7 +351,7 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered(double* __
                                                                      const MailboxDev M, int wait_parity,
                                                                      unsigned long long wait_gen,
                                                                      const double* __restrict__ fold_partials,
-                                                                     int n_fold)
+                                                                     int n_fold, const unsigned* totals_failed)
 {
   __shared__ double s_wave[4];
   if (M.world > 0)
@@ -368,9 +368,15 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered(double* __
         sc->v[0] = tot;
       mb_post_total(M, wait_parity, wait_gen, tot);
     }
-    // ... then every block waits until all peers' totals of this update are in
-    mb_block_wait(M, mb_tot_gen(M.peer[M.rank], wait_parity, 0), wait_gen);
+    // ... then every block waits until all peers' totals of this update are in.  If they are not (a peer stalled past
+    // the bound), the weights stay as the scoring stage left them -- scored, not normalised, the local total in
+    // scalars[0] -- and the host finishes the update over its other transport.
+    if (!mb_block_wait(M, mb_tot_gen(M.peer[M.rank], wait_parity, 0), wait_gen, 0))
+      return;
   }
+  else if (totals_failed != nullptr &&
+           __hip_atomic_load(totals_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    return;  // the one-block k_mailbox_wait in front of this launch ran out of time: same rule
   double total = 0.0;
   for (int r = 0; r < world; ++r)
     total += totals[r];
@@ -915,6 +921,13 @@ __device__ __forceinline__ bool draw_window_column(const WindowArgs& A, int o, l
   }
   const bool last = A.rank == A.world - 1;
   const bool mine = (r >= offset) && (r < top || last);
+  if (mine && A.n_src <= 0)
+  {
+    // an empty shard (uneven first split, or fewer samples than ranks after a resample) owns no particle: a draw that
+    // rounding sends here is the reference's failed search (ROS_ASSERT(i < sample_count)); no pose is read
+    atomicExch(A.flags, 1);
+    return false;
+  }
   if (mine)
   {
     int i;
@@ -1071,7 +1084,7 @@ __global__ void k_publish_window_keys(const long long* window, int stride, int n
                                       const MailboxDev M, int wait_parity, unsigned long long wait_gen)
 {
   if (M.world > 0)
-    mb_block_wait(M, mb_win_done(M.peer[M.rank], wait_parity, 0), wait_gen);
+    (void)mb_block_wait(M, mb_win_done(M.peer[M.rank], wait_parity, 0), wait_gen, 1);  // (the host checks the flag)
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n)
   {
@@ -1087,7 +1100,7 @@ __global__ void k_window_keys_to_aos(const long long* window, int stride, int n,
                                      const MailboxDev M, int wait_parity, unsigned long long wait_gen)
 {
   if (M.world > 0)
-    mb_block_wait(M, mb_win_done(M.peer[M.rank], wait_parity, 0), wait_gen);
+    (void)mb_block_wait(M, mb_win_done(M.peer[M.rank], wait_parity, 0), wait_gen, 1);  // (the host checks the flag)
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n)
   {

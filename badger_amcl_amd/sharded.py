@@ -95,6 +95,15 @@ class HipShardBackend:
     def mailbox_destroy(self):
         self.e.lib.bpf_shard_mailbox_destroy(self.e.h)
 
+    def mailbox_set_timeout_ms(self, ms):
+        self.e.check(self.e.lib.bpf_shard_mailbox_set_timeout_ms(self.e.h, int(ms)))
+
+    def mailbox_error_stage(self):
+        """(totals wait failed, window wait failed) of the mailbox in use; drains the stream first."""
+        a, b = C.c_int(), C.c_int()
+        self.e.check(self.e.lib.bpf_shard_mailbox_error_stage(self.e.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
+
     def _mb_view(self, ptr, shape, typestr):
         v = self._mb_views.get(ptr)
         if v is None:
@@ -262,6 +271,9 @@ class HipShardBackend:
     def max_samples(self):
         return self.pf.max_samples
 
+    def max_beams(self):
+        return getattr(self.sc, "max_beams", 2)
+
     def state(self):
         return self.pf.getState()
 
@@ -274,8 +286,12 @@ class ShardedState:
 class ShardedFilter:
     """ParticleFilter::updateSensor / updateResample over W shards (see module docstring)."""
 
-    def __init__(self, backend, dist, rank=None, world=None, first_window=4096, exchange="auto"):
+    def __init__(self, backend, dist, rank=None, world=None, first_window=4096, exchange="auto",
+                 mailbox_timeout_ms=None):
         self.b = backend
+        self.mailbox_timeout_ms = mailbox_timeout_ms
+        self.recoveries = 0  # exchanges that ran out of time and were finished over the collectives
+        self._step = 0       # resamples completed (the ranks compare it when they recover)
         self.dist = dist
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
@@ -322,6 +338,8 @@ class ShardedFilter:
     def _setup_mailbox(self):
         """True when every rank created its mailbox, mapped all the others and completed a round with them."""
         b = self.b
+        if self.mailbox_timeout_ms is not None and hasattr(b, "mailbox_set_timeout_ms"):
+            b.mailbox_set_timeout_ms(self.mailbox_timeout_ms)
         handle = b.mailbox_create(self.rank, self.world, self.max_global)
         mine = torch.tensor(list(handle if handle is not None else bytes(64)), dtype=torch.uint8, device=self.device)
         handles = self._all_gather(mine).cpu().numpy().tobytes()
@@ -334,6 +352,36 @@ class ShardedFilter:
         if not ok:
             b.mailbox_destroy()
         return ok
+
+    # ---- a mailbox wait ran out of time (a rank stalled: page-in, debugger, a long host pause)
+    def _is_exchange_error(self, err):
+        return getattr(err, "code", None) == 9  # BPF_ERR_EXCHANGE
+
+    def _recover_exchange(self):
+        """Every rank gets here after its OWN wait has run out (the rank that stalled finds its peers gone one
+        exchange later), so the collectives below are reached by all of them.  The engine's rule (badger_pf.h): after a
+        failed wait for the totals the weights are scored but NOT normalised and the local total is in the scalars;
+        a failed window wait has changed nothing of the current set.  So: drop the mailbox, all-gather the local
+        totals, normalise where that was still due, and go on with the collectives -- the interrupted resample is
+        simply run again over them.  The mailbox is set up afresh after the step."""
+        b = self.b
+        totals_failed, _ = b.mailbox_error_stage()
+        # meeting point of the ranks, and a check that they are recovering the same step (a time-out that fell
+        # within microseconds of the awaited word can leave them a step apart: that is reported, not papered over)
+        steps = self._all_gather(torch.tensor([self._step], dtype=torch.int64, device=self.device)).cpu().tolist()
+        if len(set(int(v) for v in steps)) != 1:
+            raise RuntimeError("sharded filter: the ranks fell out of step around a mailbox time-out: %r" % (steps,))
+        b.mailbox_destroy()
+        self.mailbox = False
+        self._windows.clear()
+        self._pose_views.clear()
+        totals = self._all_gather(b.local_total()).clone()
+        if totals_failed:
+            b.normalize(totals, self.sample_count)
+        self.totals = totals
+        self._fused_totals = False
+        self.recoveries += 1
+        self._remake_mailbox = True
 
     # ---- collectives (device tensors with nccl; staged through the host only for gloo + GPU)
     def _all_gather(self, t):
@@ -393,6 +441,11 @@ class ShardedFilter:
         if self.mailbox and not hasattr(data, "points_") and hasattr(self.b, "mailbox_update_sensor"):
             # mailbox: the exchange is inside the kernels, so the whole update is one call into the engine
             if self.b.mailbox_update_sensor(data, self.sample_count):
+                if self.b.max_beams() < 2:
+                    # PlanarScanner::updateSensor is a no-op then (planar_scanner.cpp:128-129): nothing was posted
+                    self.totals = None
+                    self._fused_totals = False
+                    return
                 self.totals = self.b.mailbox_totals()
                 self._fused_totals = True
                 return
@@ -465,18 +518,40 @@ class ShardedFilter:
 
     # ---- Seam B (multinomial, w_diff == 0)
     def update_resample(self):
+        self._update_resample()
+        self._step += 1
+
+    def _update_resample(self):
         b, W = self.b, self.world
         if self.mailbox and getattr(self, "_fused_totals", False) and hasattr(b, "mailbox_update_resample"):
             # one call: CDF, windows, stop rule, adoption of this rank's share (bpf_shard_mailbox_update_resample)
             leaf_in = self._global_leaf_count() if b.resample_model() == 1 else self.leaf_count
-            M, leaf, bins, wins, hint = b.mailbox_update_resample(self.flags, self.sample_count, leaf_in,
-                                                                  self.window_hint)
+            try:
+                M, leaf, bins, wins, hint = b.mailbox_update_resample(self.flags, self.sample_count, leaf_in,
+                                                                      self.window_hint)
+            except Exception as err:  # noqa: BLE001 -- only the exchange time-out is handled, the rest goes up
+                if not self._is_exchange_error(err):
+                    raise
+                self._recover_exchange()
+                self._update_resample_stages()
+                self._finish_recovery()
+                return
             self.counts = [(M * (r + 1)) // W - (M * r) // W for r in range(W)]
             self.sample_count, self.leaf_count, self.bin_count = M, leaf, bins
             self.windows_used, self.window_hint = wins, hint
             self.totals = None
             self._fused_totals = False
             return
+        self._update_resample_stages()
+
+    def _finish_recovery(self):
+        if getattr(self, "_remake_mailbox", False):
+            self._remake_mailbox = False
+            self.mailbox = self._setup_mailbox()
+
+    def _update_resample_stages(self):
+        """updateResample stage by stage (collectives, or a mailbox with the host between the stages)."""
+        b, W = self.b, self.world
         if b.resample_model() == 1:  # PF_RESAMPLE_SYSTEMATIC
             return self._update_resample_systematic()
         b.build_cdf(self.flags)

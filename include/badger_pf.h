@@ -427,6 +427,14 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
  *            bpf_shard_systematic_window_dev given this pointer store every owned column into all peers' copies, and
  *            the first consumer (bpf_kld_feed_dev / bpf_kld_insert_dev / bpf_kld_stop_dev) waits for all shards.
  *            The window stays valid until the next-but-one call; copy out what has to live longer. */
+/* A wait is bounded (default 5 s; set before create / connect).  When a bound runs out the consumer kernel leaves its
+ * data alone -- after a failed wait for the totals the weights stay scored but NOT normalised, the local total in
+ * bpf_shard_scalars_dev [0]; a failed window wait touches nothing of the current set -- and the next host check returns
+ * BPF_ERR_EXCHANGE.  bpf_shard_mailbox_error_stage says which exchange it was, so that a driver can finish the update
+ * over its other transport (all-gather the local totals, bpf_shard_normalize_dev, resample with collectives) and set
+ * the mailbox up again: badger_amcl_amd/sharded.py does exactly that. */
+int bpf_shard_mailbox_set_timeout_ms(bpf_engine* e, int timeout_ms);
+int bpf_shard_mailbox_error_stage(bpf_engine* e, int* totals_failed, int* window_failed);
 #define BPF_MAILBOX_HANDLE_BYTES 64
 int bpf_shard_mailbox_create(bpf_engine* e, int rank, int world, long long max_window, void* handle_out);
 int bpf_shard_mailbox_connect(bpf_engine* e, const void* handles);

@@ -517,3 +517,82 @@ def test_three_ranks_mailbox_equal_single_engine(tmp_path):
         for k in range(W):
             assert rr[k]["samples"].shape[0] == (M * (k + 1)) // W - (M * k) // W
     e.close()
+
+
+def _stall_worker(rank, world, port, out_dir, stall_rank):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import badger_amcl_amd as bpf
+    from badger_amcl_amd.sharded import HipShardBackend, ShardedFilter
+    from scenario import Scenario
+    orc, sc = _scenario("converged")
+    n = sc.samples.shape[0]
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    e = bpf.Engine(0)
+    shard = Scenario.__new__(Scenario)
+    shard.__dict__.update(sc.__dict__)
+    shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
+    m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    b = HipShardBackend(e, scn, pf, torch.device("cuda", 0))
+    sf = ShardedFilter(b, dist, first_window=1024, exchange="mailbox", mailbox_timeout_ms=700)
+    assert sf.mailbox
+    od = bpf.Odom(e)
+    od.setModel(*ODOM)
+    recs = []
+    for cycle in range(3):
+        if cycle == 1 and rank == stall_rank:
+            time.sleep(2.5)  # a host stall well past the mailbox bound: the peer's wait for this rank's total runs out
+        sf.update_action(od, bpf.OdomData(*ODATA))
+        sf.update_sensor(data)
+        sf.update_resample()
+        st = sf.state()
+        recs.append(dict(samples=pf.getCurrentSet().samples.copy(), M=st.sample_count, leaf=st.leaf_count,
+                         bins=st.bin_count, rng=pf.getRngState(), recoveries=sf.recoveries, mailbox=sf.mailbox))
+    np.save(os.path.join(out_dir, "stall%d.npy" % rank), np.array(recs, dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    e.close()
+
+
+@pytest.mark.timeout(240)
+def test_a_rank_stalling_past_the_mailbox_bound_does_not_kill_the_filter(tmp_path):
+    """a mailbox time-out used to be permanent and one-sided.  Now the consumer kernel of a failed wait
+    leaves its data alone, every rank finds out within its own bound, they meet, finish the interrupted update over
+    the collectives (normalising where that was still due, running the resample again), and set the mailbox up
+    again.  Rank 1 sleeps 2.5 s before its second cycle with a 0.7 s bound; all three cycles must equal the
+    undisturbed single-engine run."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_stall_worker, args=(2, port, str(tmp_path), 1), nprocs=2, join=True)
+    recs = [np.load(os.path.join(str(tmp_path), "stall%d.npy" % r), allow_pickle=True) for r in range(2)]
+    import badger_amcl_amd as bpf
+    orc, sc = _scenario("converged")
+    n = sc.samples.shape[0]
+    e = bpf.Engine(0)
+    m, scn, pf, data = sc.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
+    od = bpf.Odom(e)
+    od.setModel(*ODOM)
+    for cycle in range(3):
+        od.updateAction(pf, bpf.OdomData(*ODATA))
+        scn.updateSensor(pf, data)
+        pf.updateResample()
+        st = pf.getState()
+        cur = pf.getCurrentSet()
+        r0, r1 = recs[0][cycle], recs[1][cycle]
+        for r in (r0, r1):
+            assert (r["M"], r["leaf"], r["bins"], r["rng"]) == (st.sample_count, st.leaf_count, st.bin_count,
+                                                                 pf.getRngState()), cycle
+        merged = np.concatenate([r0["samples"], r1["samples"]])
+        assert np.array_equal(merged[:, :3], cur.samples[:, :3]), cycle
+    assert recs[0][2]["recoveries"] == 1 and recs[1][2]["recoveries"] == 1
+    assert recs[0][0]["recoveries"] == 0
+    assert recs[0][2]["mailbox"] and recs[1][2]["mailbox"]  # set up again after the step
+    e.close()
