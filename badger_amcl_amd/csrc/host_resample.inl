@@ -69,7 +69,10 @@ int launch_normalize_cdf(bpf_engine* e, double* w, int n)
   A.coarse_shift = fused_coarse_shift(n);
   HIPCHK(e, e->d_cdf_coarse.reserve((size_t)kFusedCoarse + 2));
   A.coarse = e->d_cdf_coarse.p;
-  A.guide = nullptr;  // k_resample_block searches through the subsample; the general path bisects without a head start
+  // k_resample_block searches through the subsample; the guide table is for the general path's draw kernel, worth its
+  // writes only when a long draw stream is expected (the previous resample ran to the end: a spread cloud)
+  const bool want_guide = e->window_hint >= e->max_samples;
+  A.guide = want_guide ? e->d_cdf_guide.p : nullptr;
   A.zero_word = e->d_flags.p;
   ProfScope ps(e, BPF_K_NORMALIZE);
   hipLaunchKernelGGL(k_normalize_cdf, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, A);
@@ -77,7 +80,7 @@ int launch_normalize_cdf(bpf_engine* e, double* w, int n)
   e->tile_sums_n = -1;
   e->cdf_ready_n = n;
   e->cdf_coarse_n = n;
-  e->cdf_guide_valid = false;
+  e->cdf_guide_valid = want_guide;
   return BPF_OK;
 }
 

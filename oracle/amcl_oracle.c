@@ -1623,3 +1623,154 @@ double orc_cloud_apply(const orc_cloud* p, const orc_map3d* m, double* s, int n,
   }
   return total;
 }
+
+
+/* ====================================================================================================
+ * Message shaping either side of the hot path.  Restated from the node
+ * sources; the tf2 pieces (third party, unpinned) from their published form.
+ * ==================================================================================================== */
+
+/* Node2D::updateLatestScanData, node_2d.cpp:531-560.  range_max_ is a double member assigned from a float
+ * expression (std::min<float>), range_min likewise; short readings are mapped to max range (:552-555). */
+void orc_wire_laserscan_to_planar(const float* scan_ranges, int range_count, float scan_range_min, float scan_range_max,
+                                  double sensor_min_range, double sensor_max_range, double angle_min,
+                                  double angle_increment, double* ranges_out, double* angles_out, double* range_max_out)
+{
+  double data_range_max; /* latest_scan_data_->range_max_ */
+  if (sensor_max_range > 0.0) /* :535-538 */
+  {
+    const float cap = (float)sensor_max_range;
+    const float m = (cap < scan_range_max) ? cap : scan_range_max; /* std::min(a, b) = b < a ? b : a, in float */
+    data_range_max = m;
+  }
+  else
+    data_range_max = scan_range_max;
+  double range_min; /* :539-543 */
+  if (sensor_min_range > 0.0)
+  {
+    const float lim = (float)sensor_min_range;
+    const float m = (scan_range_min < lim) ? lim : scan_range_min; /* std::max(a, b) = a < b ? b : a, in float */
+    range_min = m;
+  }
+  else
+    range_min = scan_range_min;
+  for (int i = 0; i < range_count; i++) /* :546-559 */
+  {
+    if (scan_ranges[i] <= range_min)
+      ranges_out[i] = data_range_max;
+    else
+      ranges_out[i] = scan_ranges[i];
+    angles_out[i] = angle_min + (i * angle_increment);
+  }
+  *range_max_out = data_range_max;
+}
+
+/* tf2::Quaternion::setRPY (tf2 LinearMath/Quaternion.h), the general form */
+static void tf2_set_rpy(double roll, double pitch, double yaw, double q[4])
+{
+  const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+  const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+  q[0] = sr * cp * cy - cr * sp * sy;
+  q[1] = cr * sp * cy + sr * cp * sy;
+  q[2] = cr * cp * sy - sr * sp * cy;
+  q[3] = cr * cp * cy + sr * sp * sy;
+}
+
+/* tf2 operator*(const Quaternion&, const Quaternion&) */
+static void tf2_quat_mul(const double a[4], const double b[4], double o[4])
+{
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+/* tf2::getYaw -> tf2::impl::getYaw (tf2/impl/utils.h) */
+static double tf2_get_yaw(const double q[4])
+{
+  const double sqx = q[0] * q[0], sqy = q[1] * q[1], sqz = q[2] * q[2], sqw = q[3] * q[3];
+  const double sarg = -2 * (q[0] * q[2] - q[3] * q[1]) / (sqx + sqy + sqz + sqw);
+  if (sarg <= -0.99999)
+    return -2 * atan2(q[1], q[0]);
+  if (sarg >= 0.99999)
+    return 2 * atan2(q[1], q[0]);
+  return atan2(2 * (q[0] * q[1] + q[3] * q[2]), sqw + sqx - sqy - sqz);
+}
+
+/* Node2D::getAngleStats, node_2d.cpp:497-529; tf2::doTransform on a Quaternion message multiplies by the
+ * transform's rotation from the left (tf2_geometry_msgs). */
+void orc_wire_scan_angle_stats(double scan_angle_min, double scan_angle_increment, const double q_base_scanner[4],
+                               double* angle_min_out, double* angle_increment_out)
+{
+  double min_q[4], inc_q[4], tmin[4], tinc[4];
+  tf2_set_rpy(0.0, 0.0, scan_angle_min, min_q);                          /* :504-505 */
+  tf2_set_rpy(0.0, 0.0, scan_angle_min + scan_angle_increment, inc_q);   /* :506-507 */
+  tf2_quat_mul(q_base_scanner, min_q, tmin);                             /* :515 */
+  tf2_quat_mul(q_base_scanner, inc_q, tinc);                             /* :516 */
+  *angle_min_out = tf2_get_yaw(tmin);                                    /* :527 */
+  *angle_increment_out = tf2_get_yaw(tinc) - *angle_min_out;             /* :528 */
+  *angle_increment_out = orc_normalize_angle(*angle_increment_out);      /* :530 */
+}
+
+/* Node2D::convertMap, node_2d.cpp:265-295 */
+void orc_wire_convert_map(const int8_t* data, int width, int height, double msg_resolution, double origin_x,
+                          double origin_y, int map_scale_up_factor, int32_t* cells_out, int size_out[2],
+                          float origin_out[2], double* resolution_out)
+{
+  const double resolution = msg_resolution / map_scale_up_factor;
+  size_out[0] = width * map_scale_up_factor;
+  size_out[1] = height * map_scale_up_factor;
+  const double x_origin = origin_x + (size_out[0] / 2) * resolution;
+  const double y_origin = origin_y + (size_out[1] / 2) * resolution;
+  origin_out[0] = (float)x_origin; /* pcl::PointXYZ(x_origin, y_origin, 0.0): float members */
+  origin_out[1] = (float)y_origin;
+  for (int y = 0; y < size_out[1]; y++)
+  {
+    int i = y * size_out[0];
+    const int msg_row = (y / map_scale_up_factor) * width;
+    for (int x = 0; x < size_out[0]; x++, i++)
+    {
+      const int msg_i = msg_row + x / map_scale_up_factor;
+      if (data[msg_i] == 0)
+        cells_out[i] = -1; /* CELL_FREE */
+      else if (data[msg_i] == 100)
+        cells_out[i] = 1;  /* CELL_OCCUPIED */
+      else
+        cells_out[i] = 0;  /* CELL_UNKNOWN */
+    }
+  }
+  *resolution_out = resolution;
+}
+
+/* Node3D::updateLatestScanData, node_3d.cpp:467-480 */
+int orc_wire_decimate_cloud(const float* points_xyz, int data_count, int max_beams, float* out_xyz)
+{
+  int step = (data_count - 1) / (max_beams - 1);
+  if (step < 1)
+    step = 1;
+  int kept = 0;
+  for (int i = 0; i < data_count; i += step)
+  {
+    memcpy(&out_xyz[3 * kept], &points_xyz[3 * i], 3 * sizeof(float));
+    kept++;
+  }
+  return kept;
+}
+
+/* Node::publishParticleCloud, node.cpp:335-357: q.setRPY(0, 0, yaw); tf2::toMsg(Transform(q, (x, y, 0))) */
+void orc_wire_pose_array(const double* samples, int sample_count, double* poses7_out)
+{
+  for (int i = 0; i < sample_count; i++)
+  {
+    double q[4];
+    tf2_set_rpy(0.0, 0.0, samples[4 * i + 2], q);
+    double* o = &poses7_out[7 * i];
+    o[0] = samples[4 * i];
+    o[1] = samples[4 * i + 1];
+    o[2] = 0;
+    o[3] = q[0];
+    o[4] = q[1];
+    o[5] = q[2];
+    o[6] = q[3];
+  }
+}

@@ -234,6 +234,23 @@ typedef struct
 double orc_cloud_apply(const orc_cloud* p, const orc_map3d* m, double* samples, int sample_count,
                        const float* points, int n_points, long* stats);
 
+/* ---- ROS-facing message shaping either side of the path ---- */
+/* Node2D::updateLatestScanData, node_2d.cpp:531-560 */
+void orc_wire_laserscan_to_planar(const float* scan_ranges, int range_count, float scan_range_min, float scan_range_max,
+                                  double sensor_min_range, double sensor_max_range, double angle_min,
+                                  double angle_increment, double* ranges_out, double* angles_out, double* range_max_out);
+/* Node2D::getAngleStats, node_2d.cpp:497-529, given the rotation of the base <- scanner transform (x, y, z, w) */
+void orc_wire_scan_angle_stats(double scan_angle_min, double scan_angle_increment, const double q_base_scanner[4],
+                               double* angle_min_out, double* angle_increment_out);
+/* Node2D::convertMap, node_2d.cpp:265-295: cells (MapCellState as int), size, float origin, resolution */
+void orc_wire_convert_map(const int8_t* data, int width, int height, double msg_resolution, double origin_x,
+                          double origin_y, int map_scale_up_factor, int32_t* cells_out, int size_out[2],
+                          float origin_out[2], double* resolution_out);
+/* Node3D::updateLatestScanData, node_3d.cpp:467-480: returns the number of points kept */
+int orc_wire_decimate_cloud(const float* points_xyz, int data_count, int max_beams, float* out_xyz);
+/* Node::publishParticleCloud, node.cpp:335-357: position (x, y, 0) + quaternion (x, y, z, w) per sample */
+void orc_wire_pose_array(const double* samples, int sample_count, double* poses7_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,18 @@ def lib():
     L.orc_cloud_apply.argtypes = [C.POINTER(Cloud), C.POINTER(Map3D), dp, C.c_int, C.POINTER(C.c_float), C.c_int,
                                   lp]
     L.orc_cloud_apply.restype = C.c_double
+    fp = C.POINTER(C.c_float)
+    L.orc_wire_laserscan_to_planar.argtypes = [fp, C.c_int, C.c_float, C.c_float, C.c_double, C.c_double, C.c_double,
+                                               C.c_double, dp, dp, dp]
+    L.orc_wire_laserscan_to_planar.restype = None
+    L.orc_wire_scan_angle_stats.argtypes = [C.c_double, C.c_double, dp, dp, dp]
+    L.orc_wire_scan_angle_stats.restype = None
+    L.orc_wire_convert_map.argtypes = [C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                       C.c_int, C.POINTER(C.c_int32), ip, fp, dp]
+    L.orc_wire_convert_map.restype = None
+    L.orc_wire_decimate_cloud.argtypes = [fp, C.c_int, C.c_int, fp]
+    L.orc_wire_pose_array.argtypes = [dp, C.c_int, dp]
+    L.orc_wire_pose_array.restype = None
     _lib = L
     return L
 
@@ -499,3 +511,48 @@ def cloud_apply(p, lut, samples, points, stats=None):
     if stats is not None:
         stats["evals"] = stats.get("evals", 0) + st[0]
     return total
+
+
+# ------------------------------------------------------------------- wire formats
+def wire_laserscan_to_planar(ranges_f32, range_min, range_max, angle_min, angle_increment, sensor_min_range=-1.0,
+                             sensor_max_range=-1.0):
+    r = np.ascontiguousarray(ranges_f32, dtype=np.float32)
+    ro, ao = np.zeros(r.size), np.zeros(r.size)
+    rmax = C.c_double()
+    lib().orc_wire_laserscan_to_planar(r.ctypes.data_as(C.POINTER(C.c_float)), r.size, range_min, range_max,
+                                       sensor_min_range, sensor_max_range, angle_min, angle_increment, _dp(ro),
+                                       _dp(ao), C.byref(rmax))
+    return ro, ao, rmax.value
+
+
+def wire_scan_angle_stats(angle_min, angle_increment, q_base_scanner):
+    q = np.ascontiguousarray(q_base_scanner, dtype=np.float64)
+    a, b = C.c_double(), C.c_double()
+    lib().orc_wire_scan_angle_stats(angle_min, angle_increment, _dp(q), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def wire_convert_map(data_i8, width, height, resolution, origin_x, origin_y, scale_up=1):
+    d = np.ascontiguousarray(data_i8, dtype=np.int8)
+    cells = np.zeros(width * scale_up * height * scale_up, dtype=np.int32)
+    size = (C.c_int * 2)()
+    origin = (C.c_float * 2)()
+    res = C.c_double()
+    lib().orc_wire_convert_map(d.ctypes.data_as(C.POINTER(C.c_int8)), width, height, resolution, origin_x, origin_y,
+                               scale_up, cells.ctypes.data_as(C.POINTER(C.c_int32)), size, origin, C.byref(res))
+    return cells.reshape(size[1], size[0]), (np.float32(origin[0]), np.float32(origin[1])), res.value
+
+
+def wire_decimate_cloud(points, max_beams):
+    p = np.ascontiguousarray(points, dtype=np.float32)
+    out = np.zeros_like(p)
+    k = lib().orc_wire_decimate_cloud(p.ctypes.data_as(C.POINTER(C.c_float)), p.shape[0], max_beams,
+                                      out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:k].copy()
+
+
+def wire_pose_array(samples):
+    s = np.ascontiguousarray(samples, dtype=np.float64)
+    out = np.zeros((s.shape[0], 7))
+    lib().orc_wire_pose_array(_dp(s), s.shape[0], _dp(out))
+    return out

@@ -189,3 +189,72 @@ def test_octomap_lut_builder_matches_oracle(engine, orc):
         pi, dr = om.getDistancesLUT()
         assert np.array_equal(pi, want.pose_indices)
         assert np.array_equal(dr, want.distance_ratios)
+
+
+def test_messages_in_poses_out_against_the_oracle(engine, orc):
+    """SURVEY 8(f) next-4, end to end on the GPU: an OccupancyGrid and a LaserScan as the node receives them go
+    through the product's wire shaping (bpf_wire_*) into the engine -- map from the converted cells, LUT built in the
+    reference's order, sensor update, resample -- and the resampled set comes out as a PoseArray; the same messages
+    through the oracle's restatements of Node2D::convertMap / getAngleStats / updateLatestScanData
+    (node_2d.cpp:265-295,497-560), its brushfire, scoring and resampler, and Node::publishParticleCloud
+    (node.cpp:335-357).  Cells, bearings, ranges exact; weights 1e-9; resampled poses and the PoseArray exact."""
+    import math
+    import badger_amcl_amd as bpf
+    from badger_amcl_amd import wire
+    # the messages: a 200 x 200 grid at 0.1 m scaled up by 2 -> the usual 400 x 400 at 0.05 m; a 181-beam scan from an
+    # upside-down scanner yawed by 0.2 rad, with short readings and a sensor range limit below the message's
+    cells400, origin = synth.make_map(400)
+    coarse = cells400[::2, ::2]
+    data = np.where(coarse == -1, 0, np.where(coarse == 1, 100, -1)).astype(np.int8).reshape(-1)
+    msg_origin = (-3.0, 1.5)
+    cells, org, res = wire.occupancy_grid_to_cells(data, 200, 200, 0.1, msg_origin[0], msg_origin[1], 2)
+    ocells, oorg, ores = orc.wire_convert_map(data, 200, 200, 0.1, msg_origin[0], msg_origin[1], 2)
+    assert np.array_equal(cells, ocells) and (org[0], org[1], res) == (oorg[0], oorg[1], ores)
+    q_mount = (math.cos(0.1), math.sin(0.1), 0.0, 0.0)  # roll pi (upside down) composed with yaw 0.2
+    a0, da = wire.scan_angle_stats(-1.5, 3.0 / 180, q_mount)
+    assert (a0, da) == orc.wire_scan_angle_stats(-1.5, 3.0 / 180, q_mount)
+    pose = np.array([msg_origin[0] + 10.1, msg_origin[1] + 10.0, 0.3])
+    true_ranges, _ = synth.cast_scan(cells, org, res, pose, 181, seed=4)
+    scan = true_ranges[::-1].astype(np.float32).copy()  # the mirrored sweep of an upside-down scanner
+    scan[::23] = np.float32(0.03)
+    ranges, angles, rmax = wire.laserscan_to_planar(scan, np.float32(0.05), np.float32(40.0), a0, da, 0.1, 25.0)
+    oranges, oangles, ormax = orc.wire_laserscan_to_planar(scan, np.float32(0.05), np.float32(40.0), a0, da, 0.1, 25.0)
+    assert np.array_equal(ranges, oranges) and np.array_equal(angles, oangles) and rmax == ormax == 25.0
+    # the engine on the product's shaping
+    n = 3000
+    samples = synth.converged_cloud(n, pose, seed=12)
+    samples[:, 3] *= np.random.default_rng(13).uniform(0.5, 1.5, n)
+    m = bpf.OccupancyMap(engine, res)
+    m.setCells(cells)
+    m.setOrigin(org)
+    m.updateDistancesLUTReference(2.0)
+    sc = bpf.PlanarScanner(engine)
+    sc.init(181, m)
+    sc.setModelLikelihoodField(0.95, 0.05, 0.2, 2.0)
+    sc.setMapFactors(*synth.MAP_FACTORS)
+    sc.setPlanarScannerPose((0.1, 0.0, 0.0))
+    pf = bpf.ParticleFilter(engine, 100, n, 0.0, 0.0, 85.0)
+    pf.srand48(3)
+    pf.initWithSamples(samples)
+    assert sc.updateSensor(pf, bpf.PlanarData(ranges, angles, rmax))
+    got_w = pf.getCurrentSet().samples[:, 3].copy()
+    pf.updateResample()
+    got = pf.getCurrentSet().samples
+    got_msg = wire.samples_to_pose_array(got)
+    # the oracle on its own shaping
+    omap = orc.OccupancyMap(ocells, ores, oorg)
+    omap.update_distances_lut(2.0)
+    assert np.array_equal(m.getDistancesLUT().reshape(-1), omap.lut.reshape(-1))
+    p = orc.planar(orc.MODEL_LF, 181, scanner_pose=(0.1, 0.0, 0.0), off_map_factor=synth.MAP_FACTORS[0],
+                   non_free_space_factor=synth.MAP_FACTORS[1], non_free_space_radius=synth.MAP_FACTORS[2],
+                   **synth.LF_DEFAULTS)
+    opf = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0, seed=3)
+    opf.set_samples(samples)
+    opf.update_sensor(lambda s, conv: orc.planar_apply(p, omap, s, oranges, oangles, ormax, conv))
+    rel = np.abs(got_w - opf.samples[:n, 3]) / opf.samples[:n, 3]
+    assert (rel > 1e-9).sum() <= 1
+    out = opf.update_resample()
+    M = out.sample_count
+    assert pf.getState().sample_count == M
+    assert np.array_equal(got[:, :3], opf.samples[:M, :3])
+    assert np.array_equal(got_msg, orc.wire_pose_array(opf.samples[:M]))
