@@ -113,6 +113,7 @@ SIGNATURES = {
     "bpf_shard_mailbox_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_longlong, _vp]),
     "bpf_shard_mailbox_connect": (C.c_int, [_vp, _vp]),
     "bpf_shard_mailbox_selftest": (C.c_int, [_vp, C.c_int]),
+    "bpf_map3d_builder_generations": (C.c_int, [_vp, _ip]),
     "bpf_shard_mailbox_set_timeout_ms": (C.c_int, [_vp, C.c_int]),
     "bpf_shard_mailbox_error_stage": (C.c_int, [_vp, _ip, _ip]),
     "bpf_shard_bootstrap": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_longlong, C.c_int, _ip]),

@@ -67,6 +67,164 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
   return BPF_OK;
 }
 
+namespace
+{
+__global__ void k_count_valid_keys(const unsigned long long* __restrict__ keys, size_t n, unsigned long long* count)
+{
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mine = (q < n && keys[q] != kLut3dNever) ? 1ull : 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine)
+    atomicAdd(count, mine);
+}
+
+// OctoMap::updateDistancesLUT on the device (kernels_lut3d.hpp): the FIFO brushfire generation by generation.
+// *handled = false when the dense working volume does not fit (2^31 cells / 1 GiB): the host builder takes over.
+int build_lut3d_device(bpf_engine* e, const int* occupied_ijk, size_t n_occupied, const int min_cells[3],
+                       const int max_cells[3], double resolution, double max_dist, bool* handled)
+{
+  *handled = false;
+  const long long w = (long long)max_cells[0] - min_cells[0] + 1, h = (long long)max_cells[1] - min_cells[1] + 1,
+                  nz = (long long)max_cells[2] - min_cells[2] + 1;
+  const long long volume = w * h * nz;
+  if (volume >= (1ll << 30) || w >= (1 << 21) || h >= (1 << 21) || nz >= (1 << 21) || n_occupied >= (1ull << 31))
+    return BPF_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipStream_t st = e->stream;
+  DevBuf<unsigned char> vol, tmp;
+  DevBuf<unsigned long long> col_first, keys_a, keys_b, counter;
+  DevBuf<int> occ, cell_a, src_a, cell_b, src_b, pushed, position, cols_a, cols_b;
+  HIPCHK(e, vol.reserve((size_t)volume));
+  HIPCHK(e, col_first.reserve((size_t)(w * h)));
+  HIPCHK(e, counter.reserve(1));
+  HIPCHK(e, hipMemsetAsync(vol.p, 0xFF, (size_t)volume, st));
+  HIPCHK(e, hipMemsetAsync(col_first.p, 0xFF, (size_t)(w * h) * sizeof(unsigned long long), st));
+  Lut3dArgs A{};
+  A.w = (int)w;
+  A.h = (int)h;
+  A.nz = (int)nz;
+  A.td = static_cast<int>(std::floor(max_dist / resolution)) + 2;  // CachedDistanceOctoMap (:152-172)
+  A.resolution = resolution;
+  A.max_dist = max_dist;
+  A.unit = max_dist / 255;
+  A.vol = vol.p;
+  A.col_first = col_first.p;
+  auto ensure_tmp = [&](size_t bytes) -> hipError_t { return tmp.reserve(bytes + 256); };
+  auto count_valid = [&](const unsigned long long* keys, size_t n, unsigned long long* out) -> int {
+    HIPCHK(e, hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), st));
+    if (n)
+      hipLaunchKernelGGL(k_count_valid_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, counter.p);
+    HIPCHK(e, hipMemcpyAsync(out, counter.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    return BPF_OK;
+  };
+  // ---- generation 0
+  size_t n_entries = 0;
+  if (n_occupied)
+  {
+    HIPCHK(e, occ.reserve(3 * n_occupied));
+    HIPCHK(e, hipMemcpyAsync(occ.p, occupied_ijk, 3 * n_occupied * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(e, keys_a.reserve(n_occupied));
+    HIPCHK(e, keys_b.reserve(n_occupied));
+    hipLaunchKernelGGL(k_lut3d_seed, dim3((unsigned)((n_occupied + 255) / 256)), dim3(256), 0, st, A, (const int*)occ.p,
+                       n_occupied, min_cells[0], min_cells[1], min_cells[2], keys_a.p);
+    size_t bytes = 0;
+    HIPCHK(e, rocprim::radix_sort_keys(nullptr, bytes, keys_a.p, keys_b.p, n_occupied, 0, 64, st));
+    HIPCHK(e, ensure_tmp(bytes));
+    HIPCHK(e, rocprim::radix_sort_keys(tmp.p, bytes, keys_a.p, keys_b.p, n_occupied, 0, 64, st));
+    unsigned long long valid = 0;
+    int rc = count_valid(keys_b.p, n_occupied, &valid);
+    if (rc != BPF_OK)
+      return rc;
+    n_entries = (size_t)valid;
+    HIPCHK(e, cell_a.reserve(std::max<size_t>(n_entries, 1)));
+    HIPCHK(e, src_a.reserve(std::max<size_t>(n_entries, 1)));
+    if (n_entries)
+      hipLaunchKernelGGL(k_lut3d_seed_entries, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, st, A,
+                         (const unsigned long long*)keys_b.p, n_entries, cell_a.p, src_a.p);
+  }
+  // ---- the brushfire, generation by generation (iterateEmptyCells)
+  DevBuf<int>*cell_cur = &cell_a, *src_cur = &src_a, *cell_nxt = &cell_b, *src_nxt = &src_b;
+  unsigned generation = 1;
+  while (n_entries > 0)
+  {
+    if (generation >= (1u << 20) || 6 * n_entries >= (1ull << 32))
+      return e->fail(BPF_ERR_CAPACITY, "3-D LUT builder: more than 2^32 attempts in one generation");
+    const size_t n_att = 6 * n_entries;
+    HIPCHK(e, keys_a.reserve(n_att));
+    HIPCHK(e, keys_b.reserve(n_att));
+    HIPCHK(e, pushed.reserve(n_att));
+    HIPCHK(e, position.reserve(n_att));
+    const dim3 grid((unsigned)((n_att + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_lut3d_attempts, grid, block, 0, st, A, (const int*)cell_cur->p, (const int*)src_cur->p, n_entries,
+                       keys_a.p);
+    size_t bytes = 0;
+    HIPCHK(e, rocprim::radix_sort_keys(nullptr, bytes, keys_a.p, keys_b.p, n_att, 0, 64, st));
+    HIPCHK(e, ensure_tmp(bytes));
+    HIPCHK(e, rocprim::radix_sort_keys(tmp.p, bytes, keys_a.p, keys_b.p, n_att, 0, 64, st));
+    HIPCHK(e, hipMemsetAsync(pushed.p, 0, n_att * sizeof(int), st));
+    hipLaunchKernelGGL(k_lut3d_fold, grid, block, 0, st, A, (const unsigned long long*)keys_b.p, n_att,
+                       (const int*)cell_cur->p, (const int*)src_cur->p, generation, pushed.p);
+    bytes = 0;
+    HIPCHK(e, rocprim::exclusive_scan(nullptr, bytes, pushed.p, position.p, 0, n_att, rocprim::plus<int>(), st));
+    HIPCHK(e, ensure_tmp(bytes));
+    HIPCHK(e, rocprim::exclusive_scan(tmp.p, bytes, pushed.p, position.p, 0, n_att, rocprim::plus<int>(), st));
+    int last[2] = { 0, 0 };
+    HIPCHK(e, hipMemcpyAsync(&last[0], position.p + (n_att - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(&last[1], pushed.p + (n_att - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    const size_t n_next = (size_t)last[0] + (size_t)last[1];
+    HIPCHK(e, cell_nxt->reserve(std::max<size_t>(n_next, 1)));
+    HIPCHK(e, src_nxt->reserve(std::max<size_t>(n_next, 1)));
+    if (n_next)
+      hipLaunchKernelGGL(k_lut3d_emit, grid, block, 0, st, A, (const int*)cell_cur->p, (const int*)src_cur->p, n_entries,
+                         (const int*)pushed.p, (const int*)position.p, cell_nxt->p, src_nxt->p);
+    HIPCHK(e, hipGetLastError());
+    std::swap(cell_cur, cell_nxt);
+    std::swap(src_cur, src_nxt);
+    n_entries = n_next;
+    ++generation;
+  }
+  // ---- the two-level layout, columns in the order of their first write
+  const size_t n_cols = (size_t)(w * h);
+  HIPCHK(e, keys_a.reserve(n_cols));
+  HIPCHK(e, keys_b.reserve(n_cols));
+  HIPCHK(e, cols_a.reserve(n_cols));
+  HIPCHK(e, cols_b.reserve(n_cols));
+  hipLaunchKernelGGL(k_lut3d_columns, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, A, keys_a.p, cols_a.p);
+  size_t bytes = 0;
+  HIPCHK(e, rocprim::radix_sort_pairs(nullptr, bytes, keys_a.p, keys_b.p, cols_a.p, cols_b.p, n_cols, 0, 64, st));
+  HIPCHK(e, ensure_tmp(bytes));
+  HIPCHK(e, rocprim::radix_sort_pairs(tmp.p, bytes, keys_a.p, keys_b.p, cols_a.p, cols_b.p, n_cols, 0, 64, st));
+  unsigned long long n_alloc = 0;
+  int rc = count_valid(keys_b.p, n_cols, &n_alloc);
+  if (rc != BPF_OK)
+    return rc;
+  const size_t n_ratios = (size_t)(n_alloc + 1) * (size_t)nz;
+  if (n_ratios > 0xffffffffull)
+    return e->fail(BPF_ERR_CAPACITY, "distance_ratios would pass the 32-bit column index range");
+  DevBuf<unsigned> d_pose;
+  DevBuf<unsigned char> d_ratios;
+  HIPCHK(e, d_pose.reserve(n_cols));
+  HIPCHK(e, d_ratios.reserve(n_ratios));
+  HIPCHK(e, hipMemsetAsync(d_pose.p, 0, n_cols * sizeof(unsigned), st));
+  hipLaunchKernelGGL(k_lut3d_layout, dim3((unsigned)((n_ratios + 255) / 256)), dim3(256), 0, st, A, (const int*)cols_b.p,
+                     (int)n_alloc, d_pose.p, d_ratios.p);
+  HIPCHK(e, hipGetLastError());
+  std::vector<uint32_t> pose_indices(n_cols);
+  std::vector<uint8_t> ratios(n_ratios);
+  HIPCHK(e, hipMemcpyAsync(pose_indices.data(), d_pose.p, n_cols * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(e, hipMemcpyAsync(ratios.data(), d_ratios.p, n_ratios, hipMemcpyDeviceToHost, st));
+  HIPCHK(e, hipStreamSynchronize(st));
+  e->lut3d_generations = (int)generation - 1;
+  *handled = true;
+  return bpf_map3d_set(e, pose_indices.data(), pose_indices.size(), ratios.data(), ratios.size(), min_cells, max_cells,
+                       resolution, max_dist);
+}
+}  // namespace
+
 int bpf_map3d_build_distances_lut(bpf_engine* e, const int* occupied_ijk, size_t n_occupied, const int min_cells[3],
                                   const int max_cells[3], double resolution, double max_dist)
 {
@@ -78,6 +236,15 @@ int bpf_map3d_build_distances_lut(bpf_engine* e, const int* occupied_ijk, size_t
                   nz = (long long)max_cells[2] - min_cells[2] + 1;
   if (w <= 0 || h <= 0 || nz <= 0 || w * h > 0x7fffffffll)
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "bad cell bounds");
+  e->lut3d_generations = 0;
+  if (!e->lut_host)
+  {
+    bool handled = false;
+    int rcd = build_lut3d_device(e, occupied_ijk, n_occupied, min_cells, max_cells, resolution, max_dist, &handled);
+    if (rcd != BPF_OK || handled)
+      return rcd;
+  }
+  // the same on the host, serially (BPF_OPT_LUT_HOST, or a map too large for the dense working volume)
   struct Cell
   {
     int i, j, k, si, sj, sk;
@@ -171,6 +338,14 @@ int bpf_map3d_build_distances_lut(bpf_engine* e, const int* occupied_ijk, size_t
     return e->fail(BPF_ERR_CAPACITY, "distance_ratios would pass the 32-bit column index range");
   return bpf_map3d_set(e, pose_indices.data(), pose_indices.size(), ratios.data(), ratios.size(), min_cells, max_cells,
                        resolution, max_dist);
+}
+
+int bpf_map3d_builder_generations(bpf_engine* e, int* generations_out)
+{
+  if (!e || !generations_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  *generations_out = e->lut3d_generations;
+  return BPF_OK;
 }
 
 int bpf_map3d_get_distances_lut(bpf_engine* e, uint32_t* pose_indices, size_t pose_capacity, size_t* n_pose_indices,

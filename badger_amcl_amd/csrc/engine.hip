@@ -19,6 +19,7 @@
 #include "device_types.hpp"
 #include "kdhist.hpp"
 #include "kernels_cloud.hpp"
+#include "kernels_lut3d.hpp"
 #include "kernels_motion.hpp"
 #include "kernels_kld.hpp"
 #include "kernels_recovery.hpp"

@@ -191,6 +191,8 @@ struct bpf_engine
   double map3_max_dist = 0.0;
   DevBuf<uint32_t> d_pose_indices;
   DevBuf<uint8_t> d_ratios, d_dense3d;
+  bool lut_host = false;      // BPF_OPT_LUT_HOST: the 3-D LUT builder on the host
+  int lut3d_generations = 0;  // FIFO generations the device builder ran (0: host)
   bool cloud_dense = true;   // BPF_OPT_CLOUD_DENSE: use the dense tiled volume when there is one
   size_t n_pose_indices = 0, n_ratios = 0;
   bool cloud_configured = false;

@@ -295,7 +295,8 @@ int resample_block(bpf_engine* e, int window, bool systematic, const double* tar
     HIPCHK(e, hipMemcpy(e->d_fused_jump.p, jt.data(), jt.size() * sizeof(FusedJump), hipMemcpyHostToDevice));
     HIPCHK(e, e->d_fused_keys.reserve(kFusedWindow));
     HIPCHK(e, e->d_fused_counter.reserve(1));
-    HIPCHK(e, hipMemset(e->d_fused_counter.p, 0, sizeof(unsigned)));
+    // on the engine's stream: a plain hipMemset may still be in flight when the first launch counts its blocks
+    HIPCHK(e, hipMemsetAsync(e->d_fused_counter.p, 0, sizeof(unsigned), e->stream));
   }
   ResampleBlockArgs A{};
   A.src = a.dev();

@@ -26,6 +26,7 @@ OPT_CDF_SERIAL, OPT_COUNT_CELLS, OPT_WINDOW_PATH, OPT_KLD_DEVICE_MIN, OPT_GRADED
 OPT_FUSED_RESAMPLE = 5
 OPT_CLOUD_DENSE = 6
 OPT_STATS_HOST = 7
+OPT_LUT_HOST = 8
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 

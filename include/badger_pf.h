@@ -199,6 +199,8 @@ enum
   BPF_OPT_STATS_HOST = 7,     /* default 0: cluster statistics on the device (order-independent fixed-point sums: equal to
                                * the reference's up to summation rounding); 1 = on the host from a copy of the set, in
                                * the reference's serial order, bit for bit */
+  BPF_OPT_LUT_HOST = 8,       /* default 0: bpf_map3d_build_distances_lut replays the reference's FIFO brushfire on the device,
+                               * generation by generation (same bytes, same column order); 1 = the serial host builder */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.
@@ -301,6 +303,8 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
 int bpf_map3d_build_distances_lut(bpf_engine* e, const int* occupied_ijk, size_t n_occupied, const int min_cells[3],
                                   const int max_cells[3], double resolution, double max_dist);
 /* copies out what the builder (or bpf_map3d_set) holds; either pointer may be NULL to query the sizes only */
+/* FIFO generations the last bpf_map3d_build_distances_lut ran on the device (0: it ran on the host) */
+int bpf_map3d_builder_generations(bpf_engine* e, int* generations_out);
 int bpf_map3d_get_distances_lut(bpf_engine* e, uint32_t* pose_indices, size_t pose_capacity, size_t* n_pose_indices,
                                 uint8_t* distance_ratios, size_t ratios_capacity, size_t* n_distance_ratios);
 /* PointCloudScanner::{init, setPointCloudModel, setPointCloudModelGompertz, setMapFactors,

@@ -124,4 +124,6 @@ def test_wire_functions_match_the_oracle():
         assert np.array_equal(wire.decimate_cloud(pts, mb), orc.wire_decimate_cloud(pts, mb))
     s = rng.normal(size=(500, 4))
     s[:, 2] = rng.uniform(-7.0, 7.0, 500)
-    assert np.array_equal(wire.samples_to_pose_array(s), orc.wire_pose_array(s))
+    got, want = wire.samples_to_pose_array(s), orc.wire_pose_array(s)
+    assert np.array_equal(got[:, :5], want[:, :5])
+    assert np.allclose(got[:, 5:], want[:, 5:], rtol=0, atol=3e-16)  # sin / cos vs sincos of the host libm: an ulp
