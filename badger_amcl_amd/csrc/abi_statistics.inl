@@ -13,6 +13,63 @@ int compute_cluster_stats_device(bpf_engine* e, bool* handled)
     return BPF_OK;
   HIPCHK(e, hipSetDevice(e->device));
   SampleSet& s = e->sets[e->cur];
+  if (n <= kStatBlockMax)
+  {
+    // the tracking regime: everything in one single-block launch (k_stats_block), the result in pinned memory
+    HIPCHK(e, e->d_stats_clusters.reserve((size_t)std::max(n, kStatBlockClusters)));
+    HIPCHK(e, e->h_stats_block.reserve(64));
+    if (!e->stats_lds_attr_set)
+    {
+      HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats_block),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStatBlockLds));
+      e->stats_lds_attr_set = true;
+    }
+    StatsBlockArgs B{};
+    B.p = s.dev();
+    B.n = n;
+    B.clusters = reinterpret_cast<ClusterDev*>(e->d_stats_clusters.p);
+    B.result_host = e->h_stats_block.p;
+    e->stats_generation = (e->stats_generation % 0x3fffffff) + 1;
+    B.generation = e->stats_generation;
+    hipLaunchKernelGGL(k_stats_block, dim3(1), dim3(1024), kStatBlockLds, e->stream, B);
+    HIPCHK(e, hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (unsigned spins = 0; !seen; ++spins)
+    {
+      seen = __atomic_load_n(e->h_stats_block.p, __ATOMIC_ACQUIRE) == B.generation;
+      if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+        break;
+      if (!seen)
+        __builtin_ia32_pause();
+    }
+    if (!seen)
+    {
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      if (__atomic_load_n(e->h_stats_block.p, __ATOMIC_ACQUIRE) != B.generation)
+        return e->fail(BPF_ERR_HIP, "k_stats_block did not publish its result");
+    }
+    if (e->h_stats_block.p[1] == 0)
+    {
+      StatsResult r;
+      std::memcpy(&r, e->h_stats_block.p + 4, sizeof(r));
+      e->stats_cluster_count = r.cluster_count;
+      e->stats_best = r.best;
+      e->stats_best_weight = r.best_weight;
+      std::memcpy(e->stats_best_pose, r.best_pose, sizeof(r.best_pose));
+      std::memcpy(e->set_mean, r.set_mean, sizeof(r.set_mean));
+      std::memcpy(e->set_cov, r.set_cov, sizeof(r.set_cov));
+      e->clusters.clear();
+      e->stats_clusters_fetched = false;
+      e->stats_on_device = true;
+      e->stats_epoch = e->set_epoch;
+      *handled = true;
+      return BPF_OK;
+    }
+    if (e->h_stats_block.p[1] >= 10)
+      return BPF_OK;  // key range / non-finite term: the host evaluation
+    // more than 1024 bins or 64 clusters in a small set: the general device path below
+  }
   unsigned table = 1024;
   while (table < 2u * (unsigned)n)
     table <<= 1;

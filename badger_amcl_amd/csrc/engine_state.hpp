@@ -359,6 +359,9 @@ struct bpf_engine
   DevBuf<StatsResult> d_stats_result;
   PinnedBuf<StatsResult> h_stats_result;
   PinnedBuf<int> h_stats_flags;
+  PinnedBuf<int> h_stats_block;     // k_stats_block: [0] generation, [1] status, [4 ..] StatsResult
+  int stats_generation = 0;
+  bool stats_lds_attr_set = false;
 
   // ---- cluster statistics (host, lazy)
   std::vector<bpf_cluster> clusters;

@@ -72,6 +72,8 @@ int launch_normalize_cdf(bpf_engine* e, double* w, int n)
   // k_resample_block searches through the subsample; the guide table is for the general path's draw kernel, worth its
   // writes only when a long draw stream is expected (the previous resample ran to the end: a spread cloud)
   const bool want_guide = e->window_hint >= e->max_samples;
+  if (getenv("BPF_DEBUG"))
+    fprintf(stderr, "[normalize_cdf] n %d window_hint %d max %d guide %d\n", n, e->window_hint, e->max_samples, (int)want_guide);
   A.guide = want_guide ? e->d_cdf_guide.p : nullptr;
   A.zero_word = e->d_flags.p;
   ProfScope ps(e, BPF_K_NORMALIZE);

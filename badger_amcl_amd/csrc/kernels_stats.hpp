@@ -487,4 +487,390 @@ __global__ __launch_bounds__(1024) void k_stats_set(const StatsArgs A, const Clu
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same statistics for a set of at most 4096 samples (the tracking regime: ~2 000 samples in ~50 bins and one or
+// two clusters) in ONE single-block launch, everything in LDS: the eleven launches above cost more than the host's
+// serial loop at that size (0.17 ms against 0.10 ms); this one does not.  Same steps, same fixed-point sums, same
+// results as the multi-launch path bit for bit.  Falls back (status != 0) when the set holds more than 1024 bins or 64
+// clusters, or a key does not fit the packing.
+constexpr int kStatBlockMax = 4096;
+constexpr int kStatBlockBins = 1024;
+constexpr int kStatBlockClusters = 64;
+constexpr size_t kStatBlockLds = (size_t)kStatBlockMax * (8 + 8 + 4 + 4);  // keys, hash table, parent, label
+
+struct StatsBlockArgs
+{
+  ParticlesDev p;
+  int n;
+  ClusterDev* clusters;        // [>= 64] device copy of the per-cluster results
+  volatile int* result_host;   // pinned: StatsResult at byte 16, status at [1], then the generation at [0]
+  int generation;
+};
+
+__device__ __forceinline__ int stats_block_find(const int* parent, int id)
+{
+  for (;;)
+  {
+    const int p = *reinterpret_cast<const volatile int*>(&parent[id]);
+    if (p == id)
+      return id;
+    id = p;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_stats_block(const StatsBlockArgs A)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int W = kStatBlockMax;
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);   // [W]
+  int* s_hash = reinterpret_cast<int*>(smem + (size_t)W * 8);                 // [2 W] earliest sample of the key in a slot
+  int* s_parent = reinterpret_cast<int*>(smem + (size_t)W * 16);              // [W] union-find, indexed by first-sample index
+  int* s_label = reinterpret_cast<int*>(smem + (size_t)W * 20);               // [W] cluster index of a root, at the root's index
+  __shared__ long long s_hi[kStatBlockClusters][kStatTerms];
+  __shared__ unsigned long long s_lo[kStatBlockClusters][kStatTerms];
+  __shared__ int s_list[kStatBlockBins];
+  __shared__ int s_wsum[16];
+  __shared__ int s_bins, s_bad, s_clusters;
+  __shared__ StatsResult s_res;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int Q = 4;
+  constexpr int kMask = 2 * W - 1;
+  for (int s = tid; s < 2 * W; s += 1024)
+    s_hash[s] = INT_MAX;
+  for (int s = tid; s < kStatBlockClusters * kStatTerms; s += 1024)
+  {
+    (&s_hi[0][0])[s] = 0;
+    (&s_lo[0][0])[s] = 0;
+  }
+  if (tid == 0)
+  {
+    s_bins = 0;
+    s_bad = 0;
+    s_clusters = 0;
+  }
+  // thread t owns samples 4t .. 4t + 3
+  const int m0 = tid * Q;
+  double x[Q], y[Q], th[Q], w[Q];
+  unsigned long long pk[Q];
+  int key[Q][3];
+  bool bad_key = false;
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+  {
+    const int m = m0 + q;
+    pk[q] = kKldEmpty;
+    if (m < A.n)
+    {
+      x[q] = A.p.x[m];
+      y[q] = A.p.y[m];
+      th[q] = A.p.th[m];
+      w[q] = A.p.w[m];
+      pose_key(x[q], y[q], th[q], key[q]);
+      if (!kld_pack(key[q], &pk[q]))
+        bad_key = true;
+      s_key[m] = pk[q];
+    }
+  }
+  __syncthreads();
+  if (bad_key)
+    s_bad = 1;
+  // ---- bins: a slot of the table holds the earliest sample with its key
+  int slot[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+  {
+    slot[q] = 0;
+    const int m = m0 + q;
+    if (m >= A.n || pk[q] == kKldEmpty)
+      continue;
+    unsigned h = (unsigned)((pk[q] * 0x9E3779B97F4A7C15ull) >> 40) & kMask;
+    for (;;)
+    {
+      int held = *reinterpret_cast<volatile int*>(&s_hash[h]);
+      if (held == INT_MAX)
+      {
+        held = atomicCAS(&s_hash[h], INT_MAX, m);
+        if (held == INT_MAX)
+          break;
+      }
+      if (s_key[held] == pk[q])
+      {
+        atomicMin(&s_hash[h], m);
+        break;
+      }
+      h = (h + 1) & kMask;
+    }
+    slot[q] = (int)h;
+  }
+  __syncthreads();
+  const bool usable = s_bad == 0;
+  bool is_first[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+  {
+    const int m = m0 + q;
+    is_first[q] = usable && m < A.n && s_hash[slot[q]] == m;
+    if (is_first[q])
+    {
+      s_parent[m] = m;  // the bin is its own root
+      const int pos = atomicAdd(&s_bins, 1);
+      if (pos < kStatBlockBins)
+        s_list[pos] = m;
+    }
+  }
+  __syncthreads();
+  const int n_bins = s_bins;
+  const bool fits = usable && n_bins <= kStatBlockBins;
+  // ---- clusters: thread b unites bin b with its occupied neighbours (26-neighbourhood, pf_kdtree.cpp:169-194)
+  if (fits && tid < n_bins)
+  {
+    const int i = s_list[tid];
+    const unsigned long long mine = s_key[i];
+    const int k0 = (int)(mine >> 40) - (1 << 23), k1 = (int)((mine >> 16) & 0xFFFFFFull) - (1 << 23),
+              k2 = (int)(mine & 0xFFFFull) - (1 << 15);
+    for (int dx = -1; dx <= 1; ++dx)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dt = -1; dt <= 1; ++dt)
+        {
+          if (!dx && !dy && !dt)
+            continue;
+          const int nk[3] = { k0 + dx, k1 + dy, k2 + dt };
+          unsigned long long npk;
+          if (!kld_pack(nk, &npk))
+            continue;
+          unsigned h = (unsigned)((npk * 0x9E3779B97F4A7C15ull) >> 40) & kMask;
+          int other = -1;
+          for (;;)
+          {
+            const int held = s_hash[h];
+            if (held == INT_MAX)
+              break;
+            if (s_key[held] == npk)
+            {
+              other = held;
+              break;
+            }
+            h = (h + 1) & kMask;
+          }
+          if (other < 0)
+            continue;
+          int a = stats_block_find(s_parent, i), b = stats_block_find(s_parent, other);
+          while (a != b)
+          {
+            if (a < b)
+            {
+              const int t = a;
+              a = b;
+              b = t;
+            }
+            const int old = atomicMin(&s_parent[a], b);
+            if (old == a)
+              break;
+            a = stats_block_find(s_parent, old);
+            b = stats_block_find(s_parent, b);
+          }
+        }
+  }
+  __syncthreads();
+  // ---- labels: rank of a root bin among the root bins, in sample order (prefix sum over the samples)
+  int root[Q];
+  int flags = 0, pre[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+  {
+    const int m = m0 + q;
+    root[q] = -1;
+    if (fits && m < A.n)
+      root[q] = stats_block_find(s_parent, s_hash[slot[q]]);
+    pre[q] = flags;
+    flags += (root[q] == m) ? 1 : 0;
+  }
+  int incl = flags;
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o)
+      incl += u;
+  }
+  if (lane == 63)
+    s_wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - flags;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    base += (k < wave) ? s_wsum[k] : 0;
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (root[q] == m0 + q)
+      s_label[m0 + q] = base + pre[q];
+  if (tid == 1023)
+    s_clusters = base + flags;
+  __syncthreads();
+  const int C = s_clusters;
+  const bool ok = fits && C <= kStatBlockClusters;
+  // ---- sums (32.96 fixed point, as k_stats_accumulate)
+  if (ok)
+  {
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      const int m = m0 + q;
+      const bool live = m < A.n;
+      const int cidx = live ? s_label[root[q]] : -1;
+      Fx t[kStatTerms];
+      if (live)
+      {
+        double sn, cs;
+        sincos(th[q], &sn, &cs);
+        t[0] = fx_from(w[q], &bad);
+        t[1] = fx_from(w[q] * x[q], &bad);
+        t[2] = fx_from(w[q] * y[q], &bad);
+        t[3] = fx_from(w[q] * cs, &bad);
+        t[4] = fx_from(w[q] * sn, &bad);
+        t[5] = fx_from(w[q] * x[q] * x[q], &bad);
+        t[6] = fx_from(w[q] * x[q] * y[q], &bad);
+        t[7] = fx_from(w[q] * y[q] * x[q], &bad);
+        t[8] = fx_from(w[q] * y[q] * y[q], &bad);
+        t[9].hi = 1ll << 32;
+        t[9].lo = 0;
+      }
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < kStatTerms; ++k)
+        {
+          t[k].hi = 0;
+          t[k].lo = 0;
+        }
+      }
+      const int first = __builtin_amdgcn_readfirstlane(cidx);
+      const bool uniform = __builtin_amdgcn_ballot_w64(live && cidx != first) == 0 && first >= 0;
+      if (uniform)
+      {
+#pragma unroll
+        for (int k = 0; k < kStatTerms; ++k)
+        {
+          Fx v = t[k];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1)
+          {
+            Fx u;
+            u.hi = __shfl_xor(v.hi, o, 64);
+            u.lo = __shfl_xor(v.lo, o, 64);
+            v = fx_add(v, u);
+          }
+          if (lane == 0)
+            fx_atomic_add(&s_hi[first][k], &s_lo[first][k], v);
+        }
+      }
+      else if (live && cidx >= 0)
+      {
+#pragma unroll
+        for (int k = 0; k < kStatTerms; ++k)
+          fx_atomic_add(&s_hi[cidx][k], &s_lo[cidx][k], t[k]);
+      }
+    }
+    if (bad)
+      s_bad = 2;
+  }
+  __syncthreads();
+  // ---- moments per cluster, the set's sums, the heaviest cluster (one wave: at most 64 clusters)
+  if (wave == 0)
+  {
+    const bool good = ok && s_bad == 0;
+    double bw = 0.0;
+    int bi = INT_MAX;
+    double mean0 = 0.0, mean1 = 0.0, mean2 = 0.0;
+    Fx tot[kStatTerms];
+#pragma unroll
+    for (int k = 0; k < kStatTerms; ++k)
+    {
+      tot[k].hi = 0;
+      tot[k].lo = 0;
+    }
+    if (good && lane < C)
+    {
+      double mm[kStatTerms];
+#pragma unroll
+      for (int k = 0; k < kStatTerms; ++k)
+      {
+        tot[k].hi = s_hi[lane][k];
+        tot[k].lo = s_lo[lane][k];
+        mm[k] = fx_to_double(tot[k].hi, tot[k].lo);
+      }
+      ClusterDev o;
+      o.count = (int)(s_hi[lane][9] >> 32);
+      stats_moments(mm, &o);
+      A.clusters[lane] = o;
+      mean0 = o.mean[0];
+      mean1 = o.mean[1];
+      mean2 = o.mean[2];
+      if (o.weight > 0.0)
+      {
+        bw = o.weight;
+        bi = lane;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kStatTerms; ++k)
+    {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+      {
+        Fx u;
+        u.hi = __shfl_xor(tot[k].hi, o, 64);
+        u.lo = __shfl_xor(tot[k].lo, o, 64);
+        tot[k] = fx_add(tot[k], u);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+      const double ow = __shfl_xor(bw, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ow > bw || (ow == bw && oi < bi))  // the first of equals (node_2d.cpp:608-612 keeps the first strictly larger)
+      {
+        bw = ow;
+        bi = oi;
+      }
+    }
+    const int best = (good && bw > 0.0 && bi != INT_MAX) ? bi : -1;
+    const int src_lane = best >= 0 ? best : 0;
+    const double bp0 = __shfl(mean0, src_lane, 64), bp1 = __shfl(mean1, src_lane, 64), bp2 = __shfl(mean2, src_lane, 64);
+    if (lane == 0)
+    {
+      StatsResult r;
+      r.cluster_count = C;
+      r.best = best;
+      r.best_weight = (best >= 0) ? bw : 0.0;
+      double mm[kStatTerms];
+      for (int k = 0; k < kStatTerms; ++k)
+        mm[k] = fx_to_double(tot[k].hi, tot[k].lo);
+      ClusterDev so;
+      stats_moments(mm, &so);
+      r.best_pose[0] = best >= 0 ? bp0 : 0.0;
+      r.best_pose[1] = best >= 0 ? bp1 : 0.0;
+      r.best_pose[2] = best >= 0 ? bp2 : 0.0;
+      for (int q = 0; q < 3; ++q)
+        r.set_mean[q] = so.mean[q];
+      for (int q = 0; q < 5; ++q)
+        r.set_cov[q] = so.cov[q];
+      s_res = r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // the result block goes out as ONE wave-wide store (a chain of single-word stores to host memory costs ~0.3 us each)
+    volatile int* out = A.result_host;
+    constexpr int kWords = (int)(sizeof(StatsResult) / sizeof(int));
+    static_assert(kWords <= 60, "one wave carries the result");
+    if (lane < kWords)
+      out[4 + lane] = reinterpret_cast<const int*>(&s_res)[lane];
+    if (lane == 63)
+      out[1] = good ? 0 : (s_bad ? 10 + s_bad : (fits ? 2 : 1));
+    __threadfence_system();
+    if (lane == 0)
+      __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 }  // namespace bpf

@@ -402,6 +402,8 @@ def main():
     gc.collect()
     gc.freeze()  # see the comment at the warm-up loop
     e, m, sc, pf, data, lut = setup_engine(args, wl, local_rank)
+    if os.environ.get("BPF_BENCH_FUSED") == "0":
+        e.set_option(5, 0)  # BPF_OPT_FUSED_RESAMPLE off: the separate normalise / scan / draw / tail launches (A/B runs)
 
     odom = odata = None
     if args.motion != "none":

@@ -294,3 +294,20 @@ def test_messages_in_poses_out_against_the_oracle(engine, orc):
     # sincos for the pair (glibc's sincos and its sin / cos differ by an ulp on some CPUs)
     assert np.array_equal(got_msg[:, :5], want_msg[:, :5])
     assert np.allclose(got_msg[:, 5:], want_msg[:, 5:], rtol=0, atol=3e-16)
+
+
+def test_cluster_stats_small_sets_one_block_and_beyond_its_limits(engine, orc):
+    """Sets of at most 4096 samples take the single-block kernel (k_stats_block); one with more than 64 clusters
+    (3 000 particles spread over the map: hundreds of one-bin clusters) is handed on to the general device path.  Both
+    against the oracle, and a one-sample set."""
+    sc_ = Scenario(orc, size=400, n=3000, beams=61, cloud="spread")
+    m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf", min_samples=100, seed=3)
+    sc.updateSensor(pf, data)
+    cur = pf.getCurrentSet().samples
+    want = _oracle_stats(orc, cur, 3000)
+    assert want["n"] > 64
+    _assert_stats_equal(pf, want, exact=False)
+    one = np.array([[3.0, 4.0, 0.5, 1.0]])
+    pf2 = __import__("badger_amcl_amd").ParticleFilter(engine, 1, 10, 0.0, 0.0, 85.0)
+    pf2.initWithSamples(one)
+    _assert_stats_equal(pf2, _oracle_stats(orc, one, 10), exact=False)
