@@ -157,16 +157,27 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
     rc = X.assemble(window, stride);
     if (rc != BPF_OK)
       return rc;
-    bpf_kld_reset(e);
-    rc = bpf_kld_insert_dev(e, window, stride, sys_count);  // the tree of the new set: every sample, no stop rule
-    if (rc != BPF_OK)
-      return rc;
-    bpf_kld_leaf_count(e, &leaf, &bins);
-    M = sys_count;
     *windows_out = 1;
-    rc = adopt_from(rows(window, 0), rows(window, 1), rows(window, 2));
-    if (rc != BPF_OK)
-      return rc;
+    int fused_status = BPF_FUSED_TOO_MANY_BINS;
+    if (e->fused_resample && sys_count <= kFusedWindow)
+    {
+      // tree of the new set (every sample, no stop rule), adoption and updateConverged in one launch
+      rc = shard_stop_block(e, window, stride, sys_count, true, &fused_status, &M, &leaf, &bins);
+      if (rc != BPF_OK)
+        return rc;
+    }
+    if (fused_status != BPF_FUSED_OK)
+    {
+      bpf_kld_reset(e);
+      rc = bpf_kld_insert_dev(e, window, stride, sys_count);  // the host's tree
+      if (rc != BPF_OK)
+        return rc;
+      bpf_kld_leaf_count(e, &leaf, &bins);
+      M = sys_count;
+      rc = adopt_from(rows(window, 0), rows(window, 1), rows(window, 2));
+      if (rc != BPF_OK)
+        return rc;
+    }
   }
   else
   {
@@ -181,6 +192,7 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
     int n_windows = 0;
     bool copied_any = false;
     bool have_counts = false;
+    bool adopted = false;  // k_shard_stop_block has done the stop rule and the tail
     while (m0 < max_global && stop < 0)
     {
       if (m0 > 0 && !device_declined && max_global - m0 >= device_min && need >= device_min)
@@ -225,6 +237,22 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
       rc = X.assemble(window, stride);
       if (rc != BPF_OK)
         return rc;
+      if (m0 == 0 && e->fused_resample && cnt <= kFusedWindow && *window_hint_io <= kFusedWindow)
+      {
+        // the tracking regime: the stream is expected to stop inside this first window, and the stop rule, the
+        // adoption of this rank's share and updateConverged run in one single-block launch on every rank
+        int fused_status = BPF_FUSED_TOO_MANY_BINS;
+        rc = shard_stop_block(e, window, stride, cnt, false, &fused_status, &M, &leaf, &bins);
+        if (rc != BPF_OK)
+          return rc;
+        if (fused_status == BPF_FUSED_OK)
+        {
+          ++*windows_out;
+          adopted = true;
+          break;
+        }
+        // no stop in the window, or keys / bins beyond what the kernel takes: the host replays this same window
+      }
       rc = bpf_kld_feed_dev(e, window, stride, cnt, m0, &stop);  // the one host wait of the window
       if (rc != BPF_OK)
         return rc;
@@ -253,15 +281,18 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
         win = std::max(1024, (need + need / 4 + 1023) / 1024 * 1024);
       }
     }
-    M = stop > 0 ? stop : max_global;
-    if (!have_counts)
-      bpf_kld_leaf_count(e, &leaf, &bins);
-    if (copied_any)
-      rc = adopt_from(e->d_shard_out.p, e->d_shard_out.p + max_global, e->d_shard_out.p + 2 * (size_t)max_global);
-    else
-      rc = adopt_from(rows(last_window, 0), rows(last_window, 1), rows(last_window, 2));
-    if (rc != BPF_OK)
-      return rc;
+    if (!adopted)
+    {
+      M = stop > 0 ? stop : max_global;
+      if (!have_counts)
+        bpf_kld_leaf_count(e, &leaf, &bins);
+      if (copied_any)
+        rc = adopt_from(e->d_shard_out.p, e->d_shard_out.p + max_global, e->d_shard_out.p + 2 * (size_t)max_global);
+      else
+        rc = adopt_from(rows(last_window, 0), rows(last_window, 1), rows(last_window, 2));
+      if (rc != BPF_OK)
+        return rc;
+    }
     *window_hint_io = std::max(1024, ((M + M / 4) + 1023) / 1024 * 1024);
   }
   uint64_t rng_after = 0;

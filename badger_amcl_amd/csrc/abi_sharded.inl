@@ -171,6 +171,57 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
     e->mb.fold_deferred = 0;
   }
   ProfScope ps(e, BPF_K_NORMALIZE);
+  if (wait.world > 0 && e->fused_resample && !e->cdf_serial)
+  {
+    // mailbox mode with a grid small enough to wait in-kernel: the local CDF comes out of the same launch
+    // (k_normalize_gathered_cdf), so the resample that follows starts with its draws
+    int rcb = ensure_cdf_buffers(e, n);
+    if (rcb != BPF_OK)
+      return rcb;
+    if (e->d_tile_flags.cap < (size_t)BPF_RED_BLOCK)
+    {
+      HIPCHK(e, e->d_tile_flags.reserve((size_t)BPF_RED_BLOCK));
+      HIPCHK(e, hipMemsetAsync(e->d_tile_flags.p, 0, BPF_RED_BLOCK * sizeof(unsigned), e->stream));
+      e->tile_generation = 0;
+    }
+    HIPCHK(e, e->d_cdf_coarse.reserve((size_t)kFusedCoarse + 2));
+    NormCdfGatherArgs G{};
+    G.n.w = s.w.p;
+    G.n.n = n;
+    G.n.block_partials = fold;
+    G.n.n_partials = n_fold;
+    G.n.sc = e->d_scalars.p;
+    G.n.alpha_slow = e->alpha_slow;
+    G.n.alpha_fast = e->alpha_fast;
+    G.n.tile_sums = e->d_tile_sums.p;
+    G.n.tile_flags = e->d_tile_flags.p;
+    G.n.generation = ++e->tile_generation;
+    if (G.n.generation == 0)  // wrapped: 0 is the cleared state of the flags
+      G.n.generation = ++e->tile_generation;
+    G.n.cdf = e->d_cdf.p;
+    G.n.coarse = e->d_cdf_coarse.p;
+    G.n.coarse_shift = fused_coarse_shift(n);
+    G.n.guide = nullptr;  // k_draw_window bisects the CDF itself
+    G.n.zero_word = e->d_flags.p;
+    G.totals = static_cast<const double*>(totals_dev);
+    G.world = world;
+    G.global_n = global_sample_count;
+    G.mb = wait;
+    G.wait_parity = (int)(e->mb.tot_gen & 1);
+    G.wait_gen = e->mb.tot_gen;
+    G.zero_word2 = static_cast<int*>(e->shard_flags_last);
+    G.sum_out = &e->d_scalars.p->v[7];
+    hipLaunchKernelGGL(k_normalize_gathered_cdf, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, G);
+    HIPCHK(e, hipGetLastError());
+    e->tile_sums_n = -1;
+    e->cdf_ready_n = n;
+    e->cdf_coarse_n = n;
+    e->cdf_guide_valid = false;
+    e->shard_cdf_flags = e->shard_flags_last;
+    e->shard_cdf_valid = true;
+    return BPF_OK;
+  }
+  e->shard_cdf_valid = false;
   hipLaunchKernelGGL(k_normalize_gathered, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, s.w.p, n,
                      static_cast<const double*>(totals_dev), world, global_sample_count, e->d_scalars.p,
                      e->alpha_slow, e->alpha_fast, e->d_tile_sums.p, wait, (int)(e->mb.tot_gen & 1),
@@ -186,6 +237,17 @@ int bpf_shard_build_cdf(bpf_engine* e, void* flags_dev)
   if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
+  if (e->shard_cdf_valid && e->cdf_ready_n == e->sample_count && !e->cdf_serial)
+  {
+    // k_normalize_gathered_cdf of this update left the CDF and its sum behind; it cleared the caller's miss flag too
+    // if this is the word the previous resample used
+    e->shard_cdf_valid = false;
+    if (e->shard_cdf_flags != flags_dev && flags_dev)
+      HIPCHK(e, hipMemsetAsync(flags_dev, 0, sizeof(int), e->stream));
+    e->shard_flags_last = flags_dev;
+    return BPF_OK;
+  }
+  e->shard_flags_last = flags_dev;
   // the scan clears the caller's miss flag and leaves the local CDF sum in scalars[7] itself
   return build_cdf(e, e->sets[e->cur].w.p, e->sample_count, static_cast<int*>(flags_dev), &e->d_scalars.p->v[7]);
 }
@@ -321,6 +383,102 @@ int bpf_shard_tail_small_dev(bpf_engine* e, const void* x_all_dev, const void* y
   e->conv_n = global_count;
   return BPF_OK;
 }
+
+namespace
+{
+// The sharded resample's stop rule, adoption and updateConverged in one single-block launch from an exchanged window
+// (k_shard_stop_block): *status is BPF_FUSED_OK when it was handled (the engine then holds its share of the new set),
+// another BPF_FUSED_* when the window is outside what the kernel takes -- nothing was changed and the window stays
+// readable for the stage-by-stage path.
+int shard_stop_block(bpf_engine* e, const long long* window, int stride, int count, bool systematic, int* status,
+                     int* M_out, int* leaf_out, int* bins_out)
+{
+  *status = BPF_FUSED_TOO_MANY_BINS;
+  if (count <= 0 || count > kFusedWindow || stride < count)
+    return BPF_OK;
+  if (!systematic)
+  {
+    int rc = ensure_limit_table(e, count);
+    if (rc != BPF_OK)
+      return rc;
+  }
+  HIPCHK(e, e->h_fused.reserve(32));
+  if (!e->shard_stop_attr_set)
+  {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_shard_stop_block),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+    e->shard_stop_attr_set = true;
+  }
+  SampleSet& b = e->sets[e->cur ^ 1];
+  ShardStopArgs A{};
+  A.window = window;
+  A.stride = stride;
+  A.count = count;
+  A.systematic = systematic ? 1 : 0;
+  A.max_samples = e->max_samples;
+  A.limit = e->d_kld_limit.p;
+  A.rank = e->shard_rank;
+  A.world = std::max(1, e->shard_world);
+  A.dst = b.dev();
+  A.thr = e->dist_threshold;
+  A.sc = e->d_scalars.p;
+  A.conv_count = e->d_flags.p + 1;
+  A.mb = shard_window_wait(e, window, 1);
+  A.wait_parity = (int)(e->mb.win_gen & 1);
+  A.wait_gen = e->mb.win_gen;
+  A.result_host = e->h_fused.p;
+  e->fused_generation = (e->fused_generation % 0x3fffffff) + 1;
+  A.generation = e->fused_generation;
+  A.debug = getenv("BPF_DEBUG") != nullptr;
+  {
+    ProfScope ps(e, BPF_K_FINALIZE);
+    hipLaunchKernelGGL(k_shard_stop_block, dim3(1), dim3(1024), kFusedLds, e->stream, A);
+  }
+  HIPCHK(e, hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  bool seen = false;
+  for (unsigned spins = 0; !seen; ++spins)
+  {
+    seen = __atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) == A.generation;
+    if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+      break;
+    if (!seen)
+      __builtin_ia32_pause();
+  }
+  if (!seen)
+  {
+    HIPCHK(e, hipStreamSynchronize(e->stream));  // (a mailbox wait may be running up to its bound)
+    if (__atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) != A.generation)
+      return e->fail(BPF_ERR_HIP, "k_shard_stop_block did not publish its result");
+  }
+  if (int rcx = mailbox_check(e))
+    return rcx;
+  const int* res = e->h_fused.p;
+  *status = res[4];
+  if (A.debug)
+    fprintf(stderr, "[shard stop block] count %d M %d leaf %d bins %d status %d levels %d (10 ns ticks): wait %d load %d "
+            "dedup %d tree %d scan %d tail %d\n", count, res[1], res[2], res[3], res[4], res[5], res[9] - res[8],
+            res[11] - res[9], res[12] - res[11], res[13] - res[12], res[14] - res[13], res[15] - res[14]);
+  if (res[4] != BPF_FUSED_OK)
+    return BPF_OK;
+  const int M = res[1], W = A.world;
+  const int lo = (int)(((long long)M * A.rank) / W), hi = (int)(((long long)M * (A.rank + 1)) / W);
+  if (hi - lo > e->max_samples)
+    return e->fail(BPF_ERR_CAPACITY, "adopted shard larger than max_samples");
+  *M_out = M;
+  *leaf_out = res[2];
+  *bins_out = res[3];
+  e->cur ^= 1;
+  e->sample_count = hi - lo;
+  e->leaf_count = res[2];
+  e->bin_count = res[3];
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
+  e->converged_pending = true;
+  e->conv_n = M;
+  e->hist_matches_set = false;  // no host histogram of this set
+  return BPF_OK;
+}
+}  // namespace
 
 int bpf_shard_converged_dev(bpf_engine* e, const void* x_all_dev, const void* y_all_dev, int global_count)
 {

@@ -239,6 +239,10 @@ struct bpf_engine
   unsigned tile_generation = 0;
   bool fused_resample = true; // BPF_OPT_FUSED_RESAMPLE
   bool fused_lds_attr_set = false;
+  bool shard_stop_attr_set = false;
+  bool shard_cdf_valid = false;        // k_normalize_gathered_cdf left the local CDF of the current weights behind
+  void* shard_cdf_flags = nullptr;     // the caller's miss flag that launch cleared (null: none)
+  void* shard_flags_last = nullptr;    // flags_dev of the last bpf_shard_build_cdf
   int fused_used = 0;         // the last resample ran as the one-block kernel
   int fused_generation = 0;
   PinnedBuf<int> h_fused;

@@ -38,43 +38,14 @@ struct NormCdfArgs
   int* zero_word;        // the CDF-miss flag of the draw kernels that follow
 };
 
-// grid = tiles (<= 256: thread t of a block fetches the sum of tile t), block = 256
-__global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfArgs A)
+// The tile of block b: normalise (w / total, or `uniform` when the total is not positive), publish the tile's sum, wait
+// for the tiles before it and write the tile's slice of the CDF (+ subsample, + guide).  Summation shapes of
+// k_normalize_fused (tile sum) and k_scan_final (running sums).
+__device__ __forceinline__ void normalize_tile_and_cdf(const NormCdfArgs& A, double total, double uniform, double* s_wave,
+                                                       double* s_tiles, double* s_tile_off)
 {
-  __shared__ double s_wave[4];
-  __shared__ double s_tiles[BPF_RED_BLOCK];
-  __shared__ double s_tile_off;
   const int tid = threadIdx.x, b = blockIdx.x;
-  // ---- the total: every block folds the partials with the same fixed tree (k_normalize_fused)
-  double acc = 0.0;
-  for (int i = tid; i < A.n_partials; i += BPF_RED_BLOCK)
-    acc += A.block_partials[i];
-  const double total = block_sum_256(acc, s_wave);
-  if (b == 0 && tid == 0)
-  {
-    FilterScalars* sc = A.sc;
-    sc->v[0] = total;
-    sc->v[6] = total;
-    if (total > 0.0)
-    {
-      const double w_avg = total / A.n;
-      double ws = sc->v[1], wf = sc->v[2];
-      if (ws == 0.0)
-        ws = w_avg;
-      else
-        ws += A.alpha_slow * (w_avg - ws);
-      if (wf == 0.0)
-        wf = w_avg;
-      else
-        wf += A.alpha_fast * (w_avg - wf);
-      sc->v[1] = ws;
-      sc->v[2] = wf;
-    }
-    *A.zero_word = 0;
-  }
-  // ---- normalise the tile; its sum in k_normalize_fused's shape, its running sums in k_scan_final's
   const size_t base = (size_t)b * BPF_RED_TILE + (size_t)tid * BPF_RED_PER_THREAD;
-  const double uniform = 1.0 / A.n;
   double v[BPF_RED_PER_THREAD];
   double tsum = 0.0, run = 0.0;
 #pragma unroll
@@ -109,14 +80,14 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfAr
     double off = 0.0;
     for (int t = 0; t < b; ++t)  // left to right, as k_scan_final adds them
       off += s_tiles[t];
-    s_tile_off = off;
+    *s_tile_off = off;
   }
   const double incl = wave_incl_scan(run);
   const int lane = tid & 63, wave = tid >> 6;
   if (lane == 63)
     s_wave[wave] = incl;
   __syncthreads();
-  double off = s_tile_off;
+  double off = *s_tile_off;
   for (int k = 0; k < wave; ++k)
     off += s_wave[k];
   off += incl - run;
@@ -153,6 +124,102 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfAr
         lo_c = hi_c;
       }
   }
+}
+
+// ParticleFilter::updateSensor's running averages (particle_filter.cpp:243-256) with the update's total over n samples
+__device__ __forceinline__ void update_weight_averages(FilterScalars* sc, double total, int n, double alpha_slow,
+                                                       double alpha_fast)
+{
+  if (total > 0.0)
+  {
+    const double w_avg = total / n;
+    double ws = sc->v[1], wf = sc->v[2];
+    if (ws == 0.0)
+      ws = w_avg;
+    else
+      ws += alpha_slow * (w_avg - ws);
+    if (wf == 0.0)
+      wf = w_avg;
+    else
+      wf += alpha_fast * (w_avg - wf);
+    sc->v[1] = ws;
+    sc->v[2] = wf;
+  }
+}
+
+// grid = tiles (<= 256: thread t of a block fetches the sum of tile t), block = 256
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfArgs A)
+{
+  __shared__ double s_wave[4];
+  __shared__ double s_tiles[BPF_RED_BLOCK];
+  __shared__ double s_tile_off;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  // ---- the total: every block folds the partials with the same fixed tree (k_normalize_fused)
+  double acc = 0.0;
+  for (int i = tid; i < A.n_partials; i += BPF_RED_BLOCK)
+    acc += A.block_partials[i];
+  const double total = block_sum_256(acc, s_wave);
+  if (b == 0 && tid == 0)
+  {
+    FilterScalars* sc = A.sc;
+    sc->v[0] = total;
+    sc->v[6] = total;
+    update_weight_averages(sc, total, A.n, A.alpha_slow, A.alpha_fast);
+    *A.zero_word = 0;
+  }
+  normalize_tile_and_cdf(A, total, 1.0 / A.n, s_wave, s_tiles, &s_tile_off);
+}
+
+// Sharded filter, mailbox mode (k_normalize_gathered + the CDF): block 0 folds the scoring kernel's partials into the
+// LOCAL total and posts it to every peer; every block waits for the W totals of this update, forms the global total as
+// their rank-ordered sum, normalises its tile by it and writes its slice of the local CDF.  If a peer's total does not
+// arrive in time the weights stay scored but not normalised (the rule of k_normalize_gathered) and no CDF is written.
+struct NormCdfGatherArgs
+{
+  NormCdfArgs n;             // n.n = local samples; n.block_partials / n.n_partials = the fold (may be 0: already posted)
+  const double* totals;      // this rank's mailbox slots, [world]
+  int world;
+  int global_n;
+  MailboxDev mb;
+  int wait_parity;
+  unsigned long long wait_gen;
+  int* zero_word2;           // the caller's CDF-miss flag (nullable)
+  double* sum_out;           // local CDF sum (scalars[7])
+};
+
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered_cdf(const NormCdfGatherArgs G)
+{
+  __shared__ double s_wave[4];
+  __shared__ double s_tiles[BPF_RED_BLOCK];
+  __shared__ double s_tile_off;
+  const NormCdfArgs& A = G.n;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  if (A.n_partials > 0 && b == 0)
+  {
+    double acc = 0.0;
+    for (int i = tid; i < A.n_partials; i += BPF_RED_BLOCK)
+      acc += A.block_partials[i];
+    const double tot = block_sum_256(acc, s_wave);
+    if (tid == 0)
+      A.sc->v[0] = tot;
+    mb_post_total(G.mb, G.wait_parity, G.wait_gen, tot);
+  }
+  if (!mb_block_wait(G.mb, mb_tot_gen(G.mb.peer[G.mb.rank], G.wait_parity, 0), G.wait_gen, 0))
+    return;
+  double total = 0.0;
+  for (int r = 0; r < G.world; ++r)
+    total += G.totals[r];
+  if (b == 0 && tid == 0)
+  {
+    A.sc->v[6] = total;
+    update_weight_averages(A.sc, total, G.global_n, A.alpha_slow, A.alpha_fast);
+    *A.zero_word = 0;
+    if (G.zero_word2 != nullptr)
+      *G.zero_word2 = 0;
+  }
+  normalize_tile_and_cdf(A, total, 1.0 / G.global_n, s_wave, s_tiles, &s_tile_off);
+  if (G.sum_out != nullptr && b == (int)gridDim.x - 1 && tid == (A.n - 1 - b * BPF_RED_TILE) / BPF_RED_PER_THREAD)
+    *G.sum_out = A.cdf[A.n];  // (this thread wrote it)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -316,8 +383,261 @@ __device__ __forceinline__ int fused_tree(int my, bool have, const unsigned long
   do                                                                         \
   {                                                                          \
     if (threadIdx.x == 0)                                                    \
-      s_stamp[k] = (int)(unsigned)wall_clock64();                            \
+      S.stamp[k] = (int)(unsigned)wall_clock64();                            \
   } while (0)
+
+// static LDS of the window kernels (k_resample_block and the sharded k_shard_stop_block share the stop rule below)
+struct FusedStatics
+{
+  int stop, bad, leaf, bins, count, levels, last;
+  int stamp[16];
+  int wx[16];
+  int limit[kFusedMaxBins + 1];
+  int list[kFusedMaxBins];
+  unsigned nodelta[kFusedWindow / 32];
+};
+
+// dynamic LDS (kFusedLds bytes): packed keys, the hash table (first the coarse CDF, last the tree's children), the
+// first different key per node, the staged x and y of every draw
+struct FusedLdsMap
+{
+  unsigned long long* key;  // [W]
+  int* hash;                // [2 W]
+  int* first;               // [W]
+  double* x;                // [W]
+  double* y;                // [W]
+};
+
+__device__ __forceinline__ FusedLdsMap fused_lds_map(unsigned char* smem)
+{
+  constexpr int W = kFusedWindow;
+  FusedLdsMap L;
+  L.key = reinterpret_cast<unsigned long long*>(smem);
+  L.hash = reinterpret_cast<int*>(smem + (size_t)W * 8);
+  L.first = reinterpret_cast<int*>(smem + (size_t)W * 16 + 16);
+  L.x = reinterpret_cast<double*>(smem + (size_t)W * 20 + 16);
+  L.y = L.x + W;
+  return L;
+}
+
+// what the block that holds every draw of the window clears before it loads them
+__device__ __forceinline__ void fused_stop_init(FusedStatics& S, const FusedLdsMap& L, int window, int systematic,
+                                                const int* __restrict__ limit)
+{
+  constexpr int W = kFusedWindow;
+  const int tid = threadIdx.x;
+  for (int k = tid; k <= kFusedMaxBins; k += 1024)
+    S.limit[k] = (k <= window && !systematic) ? limit[k] : INT_MAX;
+  for (int s = tid; s < W; s += 1024)
+    L.first[s] = INT_MAX;
+  for (int s = tid; s < W / 32; s += 1024)
+    S.nodelta[s] = 0u;
+  for (int s = tid; s < 2 * W; s += 1024)
+    L.hash[s] = INT_MAX;
+  if (tid == 0)
+  {
+    S.stop = INT_MAX;
+    S.bad = 0;
+    S.leaf = 0;
+    S.bins = 0;
+    S.count = 0;
+    S.levels = 0;
+  }
+}
+
+// The stop rule over the window's draws, for the block that holds all of them (keys in L.key, thread t owns draws
+// 4t .. 4t + 3: act / pk): repeated keys fold onto their first draw, the histogram tree grows over the distinct ones,
+// and the first draw m with m + 1 > resampleLimit(leaves so far) ends the set (particle_filter.cpp:411-417).  Leaves
+// S.leaf / S.bins / S.levels behind; *M_out = samples of the new set, *status_out = BPF_FUSED_*.
+__device__ __forceinline__ void fused_stop_rule(FusedStatics& S, const FusedLdsMap& L, int window, int systematic,
+                                                int max_samples, const bool (&act)[kFusedPerThread],
+                                                const unsigned long long (&pk)[kFusedPerThread], int* M_out,
+                                                int* status_out)
+{
+  constexpr int W = kFusedWindow;
+  constexpr int Q = kFusedPerThread;
+  constexpr int kHashMask = 2 * W - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m_base = tid * Q;
+  const bool usable = S.bad == 0;
+  // ---- repeated keys fold onto their first occurrence (PFKDTree::insertNode: equal key -> value +=):
+  // open-addressing table of draw indices, a slot holds the earliest draw with its key
+  bool is_first[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    is_first[q] = false;
+  if (usable)
+  {
+    int slot[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      slot[q] = 0;
+      if (!act[q])
+        continue;
+      const int m = m_base + q;
+      unsigned h = (unsigned)((pk[q] * 0x9E3779B97F4A7C15ull) >> 40) & kHashMask;
+      for (;;)
+      {
+        int held = *reinterpret_cast<volatile int*>(&L.hash[h]);
+        if (held == INT_MAX)
+        {
+          held = atomicCAS(&L.hash[h], INT_MAX, m);
+          if (held == INT_MAX)
+            break;
+        }
+        if (L.key[held] == pk[q])
+        {
+          atomicMin(&L.hash[h], m);
+          break;
+        }
+        h = (h + 1) & kHashMask;
+      }
+      slot[q] = (int)h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      is_first[q] = act[q] && L.hash[slot[q]] == m_base + q;
+      if (is_first[q])
+      {
+        const int pos = atomicAdd(&S.count, 1);
+        if (pos < kFusedMaxBins)
+          S.list[pos] = m_base + q;
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < 2 * W; s += 1024)
+      L.hash[s] = INT_MAX;
+    __syncthreads();
+  }
+  const int n_bins = S.count;
+  BPF_FUSED_STAMP(4);
+
+  // ---- the tree
+  if (usable && n_bins <= kFusedMaxBins)
+  {
+    const bool have = tid < n_bins;
+    const int my = have ? S.list[tid] : INT_MAX;
+    if (n_bins <= 64)
+    {
+      if (wave == 0)
+      {
+        const int lv = fused_tree<true>(my, have, L.key, L.first, L.hash, S.nodelta);
+        // The stop rule straight from the (at most 64) tree keys, without a scan over the draws: the leaf count only
+        // changes at a key's first draw m_k, so between two such draws it is constant and the first draw of that
+        // stretch with m + 1 > resampleLimit(leaves) (particle_filter.cpp:416) is max(m_k, limit) -- if the stretch
+        // is that long.  Every lane ranks its key against all others (values through v_readlane).
+        const int mk = have ? my : INT_MAX;
+        const int dk = (have && !((S.nodelta[my >> 5] >> (my & 31)) & 1u)) ? 1 : 0;
+        int leaf_k = 0, bins_k = 0, next_k = window;
+        for (int j = 0; j < n_bins; ++j)
+        {
+          const int mj = __builtin_amdgcn_readlane(mk, j);
+          const int dj = __builtin_amdgcn_readlane(dk, j);
+          leaf_k += (mj <= mk) ? dj : 0;
+          bins_k += (mj <= mk) ? 1 : 0;
+          next_k = (mj > mk) ? min(next_k, mj) : next_k;
+        }
+        int cand = INT_MAX;
+        if (have && !systematic)
+        {
+          const int first_over = max(mk, S.limit[min(leaf_k, kFusedMaxBins)]);
+          if (first_over < next_k)
+            cand = first_over + 1;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+          cand = min(cand, __shfl_xor(cand, off, 64));
+        const int M1 = (cand == INT_MAX ? window : cand) - 1;  // the last draw of the new set
+        if (have && mk <= M1 && M1 < next_k)
+        {
+          S.leaf = leaf_k;
+          S.bins = bins_k;
+        }
+        if (tid == 0)
+        {
+          S.levels = lv;
+          S.stop = cand;
+        }
+      }
+    }
+    else
+    {
+      const int lv = fused_tree<false>(my, have, L.key, L.first, L.hash, S.nodelta);
+      if (tid == 0)
+        S.levels = lv;
+    }
+  }
+  else if (usable && tid == 0)
+    S.bad = BPF_FUSED_TOO_MANY_BINS;
+  __syncthreads();
+  if (S.levels >= kFusedMaxLevels && tid == 0)
+    S.bad = BPF_FUSED_TOO_DEEP;
+  BPF_FUSED_STAMP(5);
+
+  // ---- more than 64 bins: leaf / bin count after every draw by prefix sums (both counts travel in one word, leaves
+  // low, bins << 16: each stays below 4097) and the first draw with m + 1 > resampleLimit(leaves)
+  const bool by_scan = !(usable && n_bins <= 64);
+  int pxy[Q];
+  int bxy = 0;
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    pxy[q] = 0;
+  if (by_scan)
+  {
+    int sxy = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      const int m = m_base + q;
+      if (is_first[q])
+        sxy += (1 << 16) + (((S.nodelta[m >> 5] >> (m & 31)) & 1u) ? 0 : 1);
+      pxy[q] = sxy;
+    }
+    const int ixy = wave_incl_scan_int(sxy);
+    if (lane == 63)
+      S.wx[wave] = ixy;
+    __syncthreads();
+    bxy = ixy - sxy;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      bxy += (k < wave) ? S.wx[k] : 0;
+  }
+  if (!systematic && by_scan)
+  {
+    int stop = INT_MAX;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      if (act[q] && stop == INT_MAX &&
+          m_base + q + 1 > S.limit[min((bxy + pxy[q]) & 0xFFFF, kFusedMaxBins)])  // particle_filter.cpp:416
+        stop = m_base + q + 1;
+    if (stop != INT_MAX)
+      atomicMin(&S.stop, stop);
+  }
+  __syncthreads();
+  int M = S.stop;
+  int status = S.bad;
+  if (M == INT_MAX)
+  {
+    M = window;
+    // no stop: fine when the window is the loop's own bound, sample_count < max_samples (:381)
+    if (!systematic && window < max_samples && status == 0)
+      status = BPF_FUSED_NO_STOP;
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (by_scan && m_base + q == M - 1)
+    {
+      S.leaf = (bxy + pxy[q]) & 0xFFFF;
+      S.bins = (bxy + pxy[q]) >> 16;
+    }
+  __syncthreads();
+  BPF_FUSED_STAMP(6);
+  *M_out = M;
+  *status_out = status;
+}
 
 // grid = ceil(window / 128) blocks of 1024 threads.  Draw phase: block b takes draws 128 b .. 128 b + 127 (its first two
 // waves, one draw per lane; a CU's texture path takes about one cache line per clock, so 4096 random gathers want to be
@@ -325,23 +645,11 @@ __device__ __forceinline__ int fused_tree(int my, bool have, const unsigned long
 __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs A)
 {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int W = kFusedWindow;
-  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);    // [W]
-  int* s_hash = reinterpret_cast<int*>(smem + (size_t)W * 8);                 // [2 W]; first the coarse CDF, last the children
-  double* s_coarse = reinterpret_cast<double*>(s_hash);                       // [W + 1] (the 16-byte pad takes entry W)
-  int* s_child = s_hash;
-  int* s_first = reinterpret_cast<int*>(smem + (size_t)W * 16 + 16);          // [W]
-  double* s_x = reinterpret_cast<double*>(smem + (size_t)W * 20 + 16);        // [W]
-  double* s_y = s_x + W;                                                      // [W]
-  __shared__ int s_stop, s_bad, s_leaf, s_bins, s_count, s_levels, s_last;
-  __shared__ int s_stamp[16];
-  __shared__ int s_wx[16];
-  __shared__ int s_limit[kFusedMaxBins + 1];
-  __shared__ int s_list[kFusedMaxBins];
-  __shared__ unsigned s_nodelta[W / 32];
+  __shared__ FusedStatics S;
+  const FusedLdsMap L = fused_lds_map(smem);
+  double* s_coarse = reinterpret_cast<double*>(L.hash);  // [W + 1] (the 16-byte pad takes entry W)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int Q = kFusedPerThread;
-  constexpr int kHashMask = 2 * W - 1;
   const bool stamps = blockIdx.x == 0;
   if (stamps)
     BPF_FUSED_STAMP(0);
@@ -376,8 +684,8 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
     BPF_FUSED_STAMP(8);
   // CDF search (first i with c[i] <= r < c[i+1], :394-398): bracket from the staged subsample, then inside it
   __shared__ int s_brk[kFusedDrawsPerBlock];
-  double* s_vals = s_x;  // [draws per block][32] (the pose staging area is idle in this phase)
-  static_assert(kFusedDrawsPerBlock * 32 <= 2 * kFusedWindow, "bracket staging must fit the s_x / s_y area");
+  double* s_vals = L.x;  // [draws per block][32] (the pose staging area is idle in this phase)
+  static_assert(kFusedDrawsPerBlock * 32 <= 2 * kFusedWindow, "bracket staging must fit the L.x / L.y area");
   int lo = 0;
   bool miss = false;
   if (drawing)
@@ -470,18 +778,18 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
   if (tid == 0)
   {
     const unsigned prev = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = prev == gridDim.x - 1;
-    if (s_last)
+    S.last = prev == gridDim.x - 1;
+    if (S.last)
       __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (!s_last)
+  if (!S.last)
   {
     if (stamps && tid == 0 && A.debug)
     {
       for (int k = 8; k < 12; ++k)
-        A.result_host[20 + k] = s_stamp[k];  // diagnostics only: block 0's draw sub-phases
-      A.result_host[20] = s_stamp[0];
+        A.result_host[20 + k] = S.stamp[k];  // diagnostics only: block 0's draw sub-phases
+      A.result_host[20] = S.stamp[0];
     }
     return;
   }
@@ -490,23 +798,7 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
   const long long shader_clk0 = clock64();
 
   // ================================================================== the last block: every draw of the window
-  for (int k = tid; k <= kFusedMaxBins; k += 1024)
-    s_limit[k] = (k <= A.window && !A.systematic) ? A.limit[k] : INT_MAX;
-  for (int s = tid; s < W; s += 1024)
-    s_first[s] = INT_MAX;
-  for (int s = tid; s < W / 32; s += 1024)
-    s_nodelta[s] = 0u;
-  for (int s = tid; s < 2 * W; s += 1024)
-    s_hash[s] = INT_MAX;  // (the coarse CDF is done with: every thread passed the barriers above)
-  if (tid == 0)
-  {
-    s_stop = INT_MAX;
-    s_bad = 0;
-    s_leaf = 0;
-    s_bins = 0;
-    s_count = 0;
-    s_levels = 0;
-  }
+  fused_stop_init(S, L, A.window, A.systematic, A.limit);
   // thread t owns draws m = 4t .. 4t + 3 from here on
   const int m_base = tid * Q;
   bool act[Q];
@@ -524,194 +816,20 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
       if (act[q])
       {
         bad_key |= pk[q] == kKldEmpty;
-        s_key[m] = pk[q];
-        s_x[m] = x;
-        s_y[m] = y;
+        L.key[m] = pk[q];
+        L.x[m] = x;
+        L.y[m] = y;
       }
     }
-    __syncthreads();  // s_bad = 0 is in place
+    __syncthreads();  // S.bad = 0 is in place
     if (bad_key)
-      s_bad = BPF_FUSED_KEY_RANGE;
+      S.bad = BPF_FUSED_KEY_RANGE;
   }
   __syncthreads();
-  const bool usable = s_bad == 0;
   BPF_FUSED_STAMP(3);
 
-  // ---- repeated keys fold onto their first occurrence (PFKDTree::insertNode: equal key -> value +=):
-  // open-addressing table of draw indices, a slot holds the earliest draw with its key
-  bool is_first[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q)
-    is_first[q] = false;
-  if (usable)
-  {
-    int slot[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-    {
-      slot[q] = 0;
-      if (!act[q])
-        continue;
-      const int m = m_base + q;
-      unsigned h = (unsigned)((pk[q] * 0x9E3779B97F4A7C15ull) >> 40) & kHashMask;
-      for (;;)
-      {
-        int held = *reinterpret_cast<volatile int*>(&s_hash[h]);
-        if (held == INT_MAX)
-        {
-          held = atomicCAS(&s_hash[h], INT_MAX, m);
-          if (held == INT_MAX)
-            break;
-        }
-        if (s_key[held] == pk[q])
-        {
-          atomicMin(&s_hash[h], m);
-          break;
-        }
-        h = (h + 1) & kHashMask;
-      }
-      slot[q] = (int)h;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-    {
-      is_first[q] = act[q] && s_hash[slot[q]] == m_base + q;
-      if (is_first[q])
-      {
-        const int pos = atomicAdd(&s_count, 1);
-        if (pos < kFusedMaxBins)
-          s_list[pos] = m_base + q;
-      }
-    }
-    __syncthreads();
-    for (int s = tid; s < 2 * W; s += 1024)
-      s_child[s] = INT_MAX;
-    __syncthreads();
-  }
-  const int n_bins = s_count;
-  BPF_FUSED_STAMP(4);
-
-  // ---- the tree
-  if (usable && n_bins <= kFusedMaxBins)
-  {
-    const bool have = tid < n_bins;
-    const int my = have ? s_list[tid] : INT_MAX;
-    if (n_bins <= 64)
-    {
-      if (wave == 0)
-      {
-        const int lv = fused_tree<true>(my, have, s_key, s_first, s_child, s_nodelta);
-        // The stop rule straight from the (at most 64) tree keys, without a scan over the draws: the leaf count only
-        // changes at a key's first draw m_k, so between two such draws it is constant and the first draw of that
-        // stretch with m + 1 > resampleLimit(leaves) (particle_filter.cpp:416) is max(m_k, limit) -- if the stretch
-        // is that long.  Every lane ranks its key against all others (values through v_readlane).
-        const int mk = have ? my : INT_MAX;
-        const int dk = (have && !((s_nodelta[my >> 5] >> (my & 31)) & 1u)) ? 1 : 0;
-        int leaf_k = 0, bins_k = 0, next_k = A.window;
-        for (int j = 0; j < n_bins; ++j)
-        {
-          const int mj = __builtin_amdgcn_readlane(mk, j);
-          const int dj = __builtin_amdgcn_readlane(dk, j);
-          leaf_k += (mj <= mk) ? dj : 0;
-          bins_k += (mj <= mk) ? 1 : 0;
-          next_k = (mj > mk) ? min(next_k, mj) : next_k;
-        }
-        int cand = INT_MAX;
-        if (have && !A.systematic)
-        {
-          const int first_over = max(mk, s_limit[min(leaf_k, kFusedMaxBins)]);
-          if (first_over < next_k)
-            cand = first_over + 1;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-          cand = min(cand, __shfl_xor(cand, off, 64));
-        const int M1 = (cand == INT_MAX ? A.window : cand) - 1;  // the last draw of the new set
-        if (have && mk <= M1 && M1 < next_k)
-        {
-          s_leaf = leaf_k;
-          s_bins = bins_k;
-        }
-        if (tid == 0)
-        {
-          s_levels = lv;
-          s_stop = cand;
-        }
-      }
-    }
-    else
-    {
-      const int lv = fused_tree<false>(my, have, s_key, s_first, s_child, s_nodelta);
-      if (tid == 0)
-        s_levels = lv;
-    }
-  }
-  else if (usable && tid == 0)
-    s_bad = BPF_FUSED_TOO_MANY_BINS;
-  __syncthreads();
-  if (s_levels >= kFusedMaxLevels && tid == 0)
-    s_bad = BPF_FUSED_TOO_DEEP;
-  BPF_FUSED_STAMP(5);
-
-  // ---- more than 64 bins: leaf / bin count after every draw by prefix sums (both counts travel in one word, leaves
-  // low, bins << 16: each stays below 4097) and the first draw with m + 1 > resampleLimit(leaves)
-  const bool by_scan = !(usable && n_bins <= 64);
-  int pxy[Q];
-  int bxy = 0;
-#pragma unroll
-  for (int q = 0; q < Q; ++q)
-    pxy[q] = 0;
-  if (by_scan)
-  {
-    int sxy = 0;
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-    {
-      const int m = m_base + q;
-      if (is_first[q])
-        sxy += (1 << 16) + (((s_nodelta[m >> 5] >> (m & 31)) & 1u) ? 0 : 1);
-      pxy[q] = sxy;
-    }
-    const int ixy = wave_incl_scan_int(sxy);
-    if (lane == 63)
-      s_wx[wave] = ixy;
-    __syncthreads();
-    bxy = ixy - sxy;
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      bxy += (k < wave) ? s_wx[k] : 0;
-  }
-  if (!A.systematic && by_scan)
-  {
-    int stop = INT_MAX;
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-      if (act[q] && stop == INT_MAX &&
-          m_base + q + 1 > s_limit[min((bxy + pxy[q]) & 0xFFFF, kFusedMaxBins)])  // particle_filter.cpp:416
-        stop = m_base + q + 1;
-    if (stop != INT_MAX)
-      atomicMin(&s_stop, stop);
-  }
-  __syncthreads();
-  int M = s_stop;
-  int status = s_bad;
-  if (M == INT_MAX)
-  {
-    M = A.window;
-    // no stop: fine when the window is the loop's own bound, sample_count < max_samples (:381)
-    if (!A.systematic && A.window < A.max_samples && status == 0)
-      status = BPF_FUSED_NO_STOP;
-  }
-#pragma unroll
-  for (int q = 0; q < Q; ++q)
-    if (by_scan && m_base + q == M - 1)
-    {
-      s_leaf = (bxy + pxy[q]) & 0xFFFF;
-      s_bins = (bxy + pxy[q]) >> 16;
-    }
-  __syncthreads();
-  BPF_FUSED_STAMP(6);
+  int M, status;
+  fused_stop_rule(S, L, A.window, A.systematic, A.max_samples, act, pk, &M, &status);
 
   // ---- weights 1 / M (:409,458-462) and updateConverged (:170-220) in k_resample_tail_small's summation shape,
   // from the poses staged in LDS
@@ -722,12 +840,12 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
     for (int i = tid; i < M; i += 1024)
     {
       A.dst.w[i] = weight;
-      ax += s_x[i];
-      ay += s_y[i];
+      ax += L.x[i];
+      ay += L.y[i];
     }
     ax = wave_sum(ax);
     ay = wave_sum(ay);
-    double* s_px = reinterpret_cast<double*>(s_key);  // the keys are done with
+    double* s_px = reinterpret_cast<double*>(L.key);  // the keys are done with
     double* s_py = s_px + 16;
     int* s_pc = reinterpret_cast<int*>(s_py + 16);
     if (lane == 0)
@@ -745,7 +863,7 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
     const double mx = sxx / M, my = syy / M;
     int cnt = 0;
     for (int i = tid; i < M; i += 1024)
-      if (fabs(s_x[i] - mx) <= A.thr && fabs(s_y[i] - my) <= A.thr)
+      if (fabs(L.x[i] - mx) <= A.thr && fabs(L.y[i] - my) <= A.thr)
         cnt++;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
@@ -771,13 +889,192 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
     {
       out[6] = (int)(clock64() - shader_clk0);
       for (int k = 0; k < 12; ++k)
-        out[8 + k] = s_stamp[k];
+        out[8 + k] = S.stamp[k];
     }
     out[1] = M;
-    out[2] = s_leaf;
-    out[3] = s_bins;
+    out[2] = S.leaf;
+    out[3] = S.bins;
     out[4] = status;
-    out[5] = s_levels;
+    out[5] = S.levels;
+    __threadfence_system();
+    __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sharded filter: the same stop rule for a draw window that every shard holds after the exchange (rows x, y, theta as
+// double bits and three int64 key rows; k_draw_window stored this shard's columns into all peers, or an integer
+// all-reduce assembled them).  One block per rank, every rank redundantly: wait for the window (mailbox mode), stop
+// rule, then this rank adopts samples [M rank / W, M (rank + 1) / W) with weights 1 / M and evaluates updateConverged
+// over all M (k_shard_tail_small's shapes).  Replaces the key copy to pinned memory, the host's ordered replay and the
+// tail launch of the stage-by-stage path.
+struct ShardStopArgs
+{
+  const long long* window;  // [6][stride]
+  int stride;
+  int count;                // draws 0 .. count - 1 (<= kFusedWindow)
+  int systematic;           // 1: the set is the whole window, no stop rule
+  int max_samples;
+  const int* limit;         // resampleLimit per leaf count, [0 .. count]
+  int rank, world;
+  ParticlesDev dst;         // this rank's other set
+  double thr;
+  FilterScalars* sc;
+  int* conv_count;
+  MailboxDev mb;            // world 0: nothing to wait for
+  int wait_parity;
+  unsigned long long wait_gen;
+  volatile int* result_host;  // pinned: [1] M, [2] leaf count, [3] bin count, [4] status, [5] levels, then [0] generation
+  int generation;
+  int debug;
+};
+
+constexpr int BPF_FUSED_EXCHANGE = 5;  // the window did not arrive (mailbox time-out): nothing was written
+
+__global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ FusedStatics S;
+  const FusedLdsMap L = fused_lds_map(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int Q = kFusedPerThread;
+  volatile int* out = A.result_host;
+  BPF_FUSED_STAMP(0);
+  if (A.mb.world > 0 && !mb_block_wait(A.mb, mb_win_done(A.mb.peer[A.mb.rank], A.wait_parity, 0), A.wait_gen, 1))
+  {
+    if (tid == 0)
+    {
+      out[4] = BPF_FUSED_EXCHANGE;
+      __threadfence_system();
+      __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  BPF_FUSED_STAMP(1);
+  fused_stop_init(S, L, A.count, A.systematic, A.limit);
+  const long long* __restrict__ wx = A.window;
+  const long long* __restrict__ wy = A.window + (size_t)A.stride;
+  const long long* __restrict__ wk = A.window + (size_t)3 * A.stride;
+  const int m_base = tid * Q;
+  bool act[Q];
+  unsigned long long pk[Q];
+  {
+    bool bad_key = false;
+    long long raw[Q][5];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      const int m = min(m_base + q, A.count - 1);
+      raw[q][0] = wx[m];
+      raw[q][1] = wy[m];
+      raw[q][2] = wk[m];
+      raw[q][3] = wk[(size_t)A.stride + m];
+      raw[q][4] = wk[(size_t)2 * A.stride + m];
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      const int m = m_base + q;
+      act[q] = m < A.count;
+      pk[q] = kKldEmpty;
+      if (act[q])
+      {
+        // the rows carry the int keys sign-extended; a value outside int cannot be packed either
+        int key[3];
+        bool fits = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+        {
+          key[d] = (int)raw[q][2 + d];
+          fits &= (long long)key[d] == raw[q][2 + d];
+        }
+        unsigned long long p1;
+        if (fits && kld_pack(key, &p1))
+          pk[q] = p1;
+        bad_key |= pk[q] == kKldEmpty;
+        L.key[m] = pk[q];
+        L.x[m] = __longlong_as_double(raw[q][0]);
+        L.y[m] = __longlong_as_double(raw[q][1]);
+      }
+    }
+    __syncthreads();  // S.bad = 0 is in place
+    if (bad_key)
+      S.bad = BPF_FUSED_KEY_RANGE;
+  }
+  __syncthreads();
+  BPF_FUSED_STAMP(3);
+
+  int M, status;
+  fused_stop_rule(S, L, A.count, A.systematic, A.max_samples, act, pk, &M, &status);
+
+  if (status == 0)
+  {
+    const int lo = (int)(((long long)M * A.rank) / A.world), hi = (int)(((long long)M * (A.rank + 1)) / A.world);
+    const long long* __restrict__ wth = A.window + (size_t)2 * A.stride;
+    const double weight = 1.0 / (double)M;
+    double ax = 0.0, ay = 0.0;
+    for (int i = tid; i < M; i += 1024)
+    {
+      const double xv = L.x[i], yv = L.y[i];
+      ax += xv;
+      ay += yv;
+      if (i >= lo && i < hi)
+      {
+        A.dst.x[i - lo] = xv;
+        A.dst.y[i - lo] = yv;
+        A.dst.th[i - lo] = __longlong_as_double(wth[i]);
+        A.dst.w[i - lo] = weight;
+      }
+    }
+    ax = wave_sum(ax);
+    ay = wave_sum(ay);
+    double* s_px = reinterpret_cast<double*>(L.key);  // the keys are done with
+    double* s_py = s_px + 16;
+    int* s_pc = reinterpret_cast<int*>(s_py + 16);
+    if (lane == 0)
+    {
+      s_px[wave] = ax;
+      s_py[wave] = ay;
+    }
+    __syncthreads();
+    double sxx = 0.0, syy = 0.0;
+    for (int k = 0; k < 16; ++k)
+    {
+      sxx += s_px[k];
+      syy += s_py[k];
+    }
+    const double mx = sxx / M, my = syy / M;
+    int cnt = 0;
+    for (int i = tid; i < M; i += 1024)
+      if (fabs(L.x[i] - mx) <= A.thr && fabs(L.y[i] - my) <= A.thr)
+        cnt++;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0)
+      s_pc[wave] = cnt;
+    __syncthreads();
+    if (tid == 0)
+    {
+      int tot = 0;
+      for (int k = 0; k < 16; ++k)
+        tot += s_pc[k];
+      *A.conv_count = tot;
+      A.sc->v[3] = sxx;
+      A.sc->v[4] = syy;
+    }
+  }
+  BPF_FUSED_STAMP(7);
+  if (tid == 0)
+  {
+    if (A.debug)
+      for (int k = 0; k < 8; ++k)
+        out[8 + k] = S.stamp[k];
+    out[1] = M;
+    out[2] = S.leaf;
+    out[3] = S.bins;
+    out[4] = status;
+    out[5] = S.levels;
     __threadfence_system();
     __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }

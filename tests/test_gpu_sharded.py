@@ -54,6 +54,11 @@ def _worker(rank, world, port, out_dir, cloud, device_min, resampler, exchange):
     shard.samples = np.ascontiguousarray(sc.samples[lo:hi])
     m, scn, pf, data = shard.gpu_objects(e, 181, "lf", min_samples=100, max_samples=n, seed=21)
     pf.setResampleModel(resampler)
+    if exchange == "mailbox-staged":
+        # the mailbox step without its single-launch forms (k_normalize_gathered_cdf, k_shard_stop_block): separate
+        # normalise / CDF launches, the host's ordered replay of the window's keys, the tail launch
+        e.set_option(5, 0)  # BPF_OPT_FUSED_RESAMPLE
+        exchange = "mailbox"
     b = HipShardBackend(e, scn, pf, torch.device("cuda", 0))
     b.kld_device_min = device_min
     sf = ShardedFilter(b, dist, first_window=1024, exchange=exchange)
@@ -76,12 +81,13 @@ def _worker(rank, world, port, out_dir, cloud, device_min, resampler, exchange):
     e.close()
 
 
-@pytest.mark.parametrize("exchange", ["mailbox", "collective"])
+@pytest.mark.parametrize("exchange", ["mailbox", "collective", "mailbox-staged"])
 @pytest.mark.parametrize("cloud,device_min,resampler", [("converged", 8192, 0), ("spread", 512, 0),
                                                         ("converged", 8192, 1)])
 def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min, resampler, exchange):
-    """converged: early KLD stop inside the first window (host replay).  spread with a low device threshold: no
-    stop in the first window, so one window with the whole stream follows and the stop rule runs on the device."""
+    """converged: early KLD stop inside the first window (mailbox: k_shard_stop_block on every rank; collective and
+    mailbox-staged: the host's ordered replay).  spread with a low device threshold: no stop in the first window, so
+    one window with the whole stream follows and the stop rule runs on the device."""
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     port = _free_port()
