@@ -240,6 +240,9 @@ struct bpf_engine
   bool fused_resample = true; // BPF_OPT_FUSED_RESAMPLE
   bool fused_lds_attr_set = false;
   bool shard_stop_attr_set = false;
+  bool kld_persistent = false;         // BPF_OPT_KLD_PERSISTENT: the device tree in one launch when its grid is resident
+  int kld_persist_blocks_per_cu = -1;  // occupancy of k_kld_tree_persistent (-1: not asked yet)
+  DevBuf<unsigned> d_kld_bar;
   bool shard_cdf_valid = false;        // k_normalize_gathered_cdf left the local CDF of the current weights behind
   void* shard_cdf_flags = nullptr;     // the caller's miss flag that launch cleared (null: none)
   void* shard_flags_last = nullptr;    // flags_dev of the last bpf_shard_build_cdf

@@ -421,6 +421,75 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   K.limit = e->d_kld_limit.p;
   const dim3 grid(blocks_for(n, 256)), block(256);
   hipLaunchKernelGGL(k_kld_hash, grid, block, 0, e->stream, K);
+  if (e->kld_persistent)
+  {
+    // the whole stream in one resident round of 1024-thread blocks: the level loop, the prefix sums and the stop test
+    // run in ONE launch with grid barriers between the levels (k_kld_tree_persistent)
+    const int pgrid = blocks_for(n, kKldBlock);
+    if (e->kld_persist_blocks_per_cu < 0)
+    {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_kld_tree_persistent),
+                                                       kKldBlock, 0) != hipSuccess)
+        nb = 0;
+      e->kld_persist_blocks_per_cu = nb;
+    }
+    if (pgrid <= e->kld_persist_blocks_per_cu * e->n_cu)
+    {
+      HIPCHK(e, e->d_kld_bar.reserve(4));
+      HIPCHK(e, e->d_kld_tiles.reserve((size_t)std::max(pgrid, tiles)));
+      HIPCHK(e, e->h_fused.reserve(32));
+      HIPCHK(e, hipMemsetAsync(e->d_kld_bar.p, 0, 4 * sizeof(unsigned), e->stream));
+      KldPersistArgs P{};
+      P.K = K;
+      P.bar = e->d_kld_bar.p;
+      P.level_waiting = e->d_kld_flags.p + 4;
+      P.tile_sums = e->d_kld_tiles.p;
+      P.max_levels = kMaxLevels;
+      P.whole_stream = whole_stream ? 1 : 0;
+      P.timeout_ticks = 2000000ll;  // 20 ms per barrier: a resident grid passes one in microseconds
+      P.result_host = e->h_fused.p;
+      e->fused_generation = (e->fused_generation % 0x3fffffff) + 1;
+      P.generation = e->fused_generation;
+      hipLaunchKernelGGL(k_kld_tree_persistent, dim3(pgrid), dim3(kKldBlock), 0, e->stream, P);
+      HIPCHK(e, hipGetLastError());
+      const auto t0 = std::chrono::steady_clock::now();
+      bool seen = false;
+      for (unsigned spins = 0; !seen; ++spins)
+      {
+        seen = __atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) == P.generation;
+        if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+          break;
+        if (!seen)
+          __builtin_ia32_pause();
+      }
+      if (!seen)
+      {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (__atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) != P.generation)
+          return e->fail(BPF_ERR_HIP, "k_kld_tree_persistent did not publish its result");
+      }
+      const int* res = e->h_fused.p;
+      if (getenv("BPF_DEBUG"))
+        fprintf(stderr, "[kld persistent] n %d blocks %d stop %d leaf %d bins %d status %d levels %d\n", n, pgrid, res[1],
+                res[2], res[3], res[4], res[5]);
+      if (res[4] == BPF_KLD_PERSIST_OK)
+      {
+        *stop_out = res[1];
+        *leaf_out = res[2];
+        *bins_out = res[3];
+        *handled = true;
+        return BPF_OK;
+      }
+      if (res[4] != BPF_KLD_PERSIST_TIMEOUT)
+        return BPF_OK;  // a key outside the packing, or deeper than the level budget: not handled (host replay)
+      // the grid was not resident as a whole (the GPU is shared with another process): let the launch drain, leave
+      // this form alone from now on and build the tree again with one launch pair per level
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      e->kld_persistent = false;
+      return kld_tree_on_device(e, maxs, handled, stop_out, leaf_out, bins_out, whole_stream);
+    }
+  }
   hipLaunchKernelGGL(k_kld_init, grid, block, 0, e->stream, K);
   hipLaunchKernelGGL(k_kld_root_first, dim3(1), dim3(1024), 0, e->stream, K);
   int level = 0;

@@ -336,4 +336,276 @@ __global__ __launch_bounds__(256) void k_kld_scan_final(const KldArgs A, const i
     atomicMin(&A.flags[2], stop);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same tree in ONE launch (opt-in, BPF_OPT_KLD_PERSISTENT): the level loop above is launch-bound (a spread cloud's
+// tree is ~40 levels deep: 80+ launches of ~7 us for microseconds of work each), so when the whole stream fits one
+// resident round of blocks the grid can stay on the chip with grid-wide barriers between the levels (every thread
+// keeps its key, its current node and its delta in registers); the prefix sums over the deltas, the stop test and the
+// counts at the stop follow in the same launch and the result goes to pinned host memory.  Exact like the other form
+// (tests run both) but NOT faster on MI355X: 0.98 ms per step of the 100 k spread cloud against 0.83 ms.  A level is
+// ~9 dependent round trips between XCDs (first[], the atomics' completion, barrier arrival, barrier release, child[],
+// atomics, barrier, barrier, level word), each 1.5-2 us through the Infinity Cache, which is what a launch boundary
+// costs as well; with fences by all threads instead of thread 0 a barrier took 45 us.
+//
+// Grid barrier: arrival counter + generation word (agent scope).  A wait is bounded: if the grid is NOT co-resident
+// after all (another process holds the CUs) the waiting blocks give up, status BPF_KLD_PERSIST_TIMEOUT is published
+// once and the host takes the launch-per-level path; every wave reaches its exit either way.
+constexpr int BPF_KLD_PERSIST_OK = 0, BPF_KLD_PERSIST_KEY_RANGE = 1, BPF_KLD_PERSIST_TOO_DEEP = 2,
+              BPF_KLD_PERSIST_TIMEOUT = 3;
+
+struct KldPersistArgs
+{
+  KldArgs K;
+  unsigned* bar;          // [0] arrivals, [1] generation, [2] "somebody gave up", [3] result published; zeroed before the launch
+  int* level_waiting;     // [max_levels] zeroed: a key still waits after level l
+  int2* tile_sums;        // [gridDim.x]
+  int max_levels;
+  int whole_stream;       // 1: the tree of all n keys, no stop rule
+  long long timeout_ticks;  // bound of one barrier wait (100 MHz wall clock)
+  volatile int* result_host;  // pinned: [1] stop (-1: none), [2] leaf count, [3] bin count, [4] status, [5] levels; [0] generation
+  int generation;
+};
+
+// Everything the blocks exchange inside the launch goes through agent-scope atomics (atomicMin into first / child,
+// atomic stores of the tile sums and level words, atomic loads on the reading side), so the barrier only has to order
+// them: the block barrier waits for every wave's outstanding memory operations, then thread 0 arrives with a release,
+// spins on the generation word and acquires.  (Fences by all 1024 threads cost ~45 us per barrier: 1 600 L2
+// write-back / invalidate requests in flight.)
+__device__ __forceinline__ int kld_ld(const int* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool kld_grid_sync(const KldPersistArgs& P, unsigned& epoch, int* s_flag)
+{
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    ++epoch;
+    int ok = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned prev = __hip_atomic_fetch_add(&P.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1)
+    {
+      __hip_atomic_store(&P.bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&P.bar[1], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else
+    {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(&P.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+      {
+        if (__hip_atomic_load(&P.bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+            wall_clock64() - t0 > P.timeout_ticks)
+        {
+          __hip_atomic_store(&P.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+__device__ __forceinline__ void kld_persist_publish(const KldPersistArgs& P, int stop, int leaf, int bins, int status,
+                                                    int levels)
+{
+  // once per launch, by whoever gets here first (the thread that holds the answer, or the first block to give up)
+  if (__hip_atomic_exchange(&P.bar[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    return;
+  volatile int* out = P.result_host;
+  out[1] = stop;
+  out[2] = leaf;
+  out[3] = bins;
+  out[4] = status;
+  out[5] = levels;
+  __threadfence_system();
+  __hip_atomic_store(const_cast<int*>(out), P.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// grid = ceil(n / 1024) blocks of 1024 threads, all resident at once (the host checks); after k_kld_hash
+__global__ __launch_bounds__(kKldBlock) void k_kld_tree_persistent(const KldPersistArgs P)
+{
+  __shared__ unsigned s_tag[kKldCombine];
+  __shared__ int s_val[kKldCombine];
+  __shared__ int s_flag;
+  __shared__ int s_red[16];
+  __shared__ int2 s_scan[16];
+  const KldArgs& A = P.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * kKldBlock + tid;
+  const bool in = i < A.n;
+  unsigned epoch = 0;
+#define KLD_SYNC_OR_QUIT()                                                       \
+  do                                                                             \
+  {                                                                              \
+    if (!kld_grid_sync(P, epoch, &s_flag))                                       \
+    {                                                                            \
+      if (tid == 0)                                                              \
+        kld_persist_publish(P, -1, 0, 0, BPF_KLD_PERSIST_TIMEOUT, 0);            \
+      return;                                                                    \
+    }                                                                            \
+  } while (0)
+
+  // ---- tree keys = first occurrences; all of them but draw 0 wait at the root and report to it
+  const bool is_first = in && A.h_tmin[A.slot[i]] == i;  // (written by the launch before)
+  int dx = is_first ? 1 : 0;
+  const int dy = dx;
+  int cur = (is_first && i != 0) ? 0 : -1;
+  {
+    int best = cur == 0 ? i : INT_MAX;
+    for (int o = 32; o > 0; o >>= 1)
+      best = min(best, __shfl_xor(best, o, 64));
+    if (lane == 0)
+      s_red[wave] = best;
+    __syncthreads();
+    if (tid == 0)
+    {
+      for (int w = 1; w < 16; ++w)
+        best = min(best, s_red[w]);
+      if (best != INT_MAX)
+        atomicMin(&A.first[0], best);
+    }
+  }
+  KLD_SYNC_OR_QUIT();
+  if (__hip_atomic_load(&A.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+  {
+    // k_kld_hash met a key outside the packing range: not handled here
+    if (i == 0)
+      kld_persist_publish(P, -1, 0, 0, BPF_KLD_PERSIST_KEY_RANGE, 0);
+    return;
+  }
+
+  // ---- the levels
+  int level = 0;
+  bool done = false;
+  for (; level < P.max_levels; ++level)
+  {
+    int f = 0, side = 0;
+    const bool waiting = cur >= 0;
+    unsigned a = 0;
+    if (waiting)
+    {
+      f = kld_ld(&A.first[cur]);
+      side = kld_side(A.keys, cur, f, i);
+      a = 2u * (unsigned)cur + (unsigned)side;
+    }
+    block_atomic_min(A.child, a, i, waiting, s_tag, s_val);
+    KLD_SYNC_OR_QUIT();
+    bool still = false;
+    int c = 0;
+    if (waiting)
+    {
+      c = kld_ld(&A.child[a]);
+      if (c == i)
+      {
+        cur = -1;  // i is a node now
+        if (f == i)
+          dx = 0;  // its creation ends the parent's time as a leaf: +1 - 1
+      }
+      else
+      {
+        cur = c;
+        still = true;
+      }
+    }
+    block_atomic_min(A.first, (unsigned)c, i, still, s_tag, s_val);
+    if (__syncthreads_or(still ? 1 : 0) && tid == 0)
+      __hip_atomic_store(&P.level_waiting[level], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    KLD_SYNC_OR_QUIT();
+    if (__hip_atomic_load(&P.level_waiting[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    {
+      done = true;
+      ++level;
+      break;
+    }
+  }
+  if (!done)
+  {
+    if (i == 0)
+      kld_persist_publish(P, -1, 0, 0, BPF_KLD_PERSIST_TOO_DEEP, level);
+    return;
+  }
+
+  // ---- (leaf count, bin count) after every draw: inclusive scan of the deltas, one 1024-tile per block
+  int2 incl = make_int2(dx, dy);
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int ux = __shfl_up(incl.x, o, 64), uy = __shfl_up(incl.y, o, 64);
+    if (lane >= o)
+    {
+      incl.x += ux;
+      incl.y += uy;
+    }
+  }
+  if (lane == 63)
+    s_scan[wave] = incl;
+  __syncthreads();
+  int2 run = incl;
+  for (int q = 0; q < wave; ++q)
+  {
+    run.x += s_scan[q].x;
+    run.y += s_scan[q].y;
+  }
+  if (tid == kKldBlock - 1)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&P.tile_sums[blockIdx.x]),
+                       ((unsigned long long)(unsigned)run.y << 32) | (unsigned)run.x, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  KLD_SYNC_OR_QUIT();
+  {
+    // the tiles before this one (a few hundred at most): strided partial sums, then the block's total
+    int2 acc = make_int2(0, 0);
+    for (int t = tid; t < (int)blockIdx.x; t += kKldBlock)
+    {
+      const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&P.tile_sums[t]),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc.x += (int)(unsigned)v;
+      acc.y += (int)(unsigned)(v >> 32);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+      acc.x += __shfl_xor(acc.x, o, 64);
+      acc.y += __shfl_xor(acc.y, o, 64);
+    }
+    __syncthreads();  // s_scan is read above
+    if (lane == 0)
+      s_scan[wave] = acc;
+    __syncthreads();
+    for (int q = 0; q < 16; ++q)
+    {
+      run.x += s_scan[q].x;
+      run.y += s_scan[q].y;
+    }
+  }
+  // the stop test (particle_filter.cpp:416: sample_count > resampleLimit(leaf_count), sample_count = i + 1)
+  if (!P.whole_stream)
+  {
+    int stop = (in && i + 1 > A.limit[run.x]) ? i + 1 : INT_MAX;
+    for (int o = 32; o > 0; o >>= 1)
+      stop = min(stop, __shfl_xor(stop, o, 64));
+    if (lane == 0)
+      s_red[wave] = stop;
+    __syncthreads();
+    if (tid == 0)
+    {
+      for (int w = 1; w < 16; ++w)
+        stop = min(stop, s_red[w]);
+      if (stop != INT_MAX)
+        atomicMin(&A.flags[2], stop);
+    }
+  }
+  KLD_SYNC_OR_QUIT();
+  const int stop = P.whole_stream ? INT_MAX : __hip_atomic_load(&A.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool stopped = stop >= 1 && stop <= A.n;
+  const int M = stopped ? stop : A.n;
+  if (i == M - 1)
+    kld_persist_publish(P, stopped ? stop : -1, run.x, run.y, BPF_KLD_PERSIST_OK, level);
+#undef KLD_SYNC_OR_QUIT
+}
+
 }  // namespace bpf

@@ -27,6 +27,7 @@ OPT_FUSED_RESAMPLE = 5
 OPT_CLOUD_DENSE = 6
 OPT_STATS_HOST = 7
 OPT_LUT_HOST = 8
+OPT_KLD_PERSISTENT = 9
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 

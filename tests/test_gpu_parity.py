@@ -160,14 +160,17 @@ def test_update_resample_matches_oracle(engine, orc, cloud, n, resampler, serial
 
 @pytest.mark.parametrize("cloud,n,pop", [("spread", 3000, None), ("converged", 3000, None), ("mixture", 20000, None),
                                          ("spread", 30000, (0.0025, 0.9975)), ("mixture", 9000, (0.05, 0.99))])
-def test_kld_stop_rule_on_device_matches_oracle(engine, orc, cloud, n, pop):
+@pytest.mark.parametrize("persistent", [0, 1])
+def test_kld_stop_rule_on_device_matches_oracle(engine, orc, cloud, n, pop, persistent):
     """The level-synchronous device build of the histogram tree (long draw streams) against the oracle's serial
     insertion: stop count, leaf count, bin count, poses and RNG state exact.  BPF_OPT_KLD_DEVICE_MIN = 1 sends
-    even these small sets through it; serial CDF so that no draw sits on a summation-order knife edge."""
+    even these small sets through it; serial CDF so that no draw sits on a summation-order knife edge.  Both forms:
+    one launch with grid barriers between the levels (k_kld_tree_persistent), and one launch pair per level."""
     import badger_amcl_amd.pf as hpf
     sc_ = Scenario(orc, size=400, n=n, beams=61, cloud=cloud)
     engine.set_option(hpf.OPT_CDF_SERIAL, 1)
     engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 1)
+    engine.set_option(hpf.OPT_KLD_PERSISTENT, persistent)
     try:
         m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf", min_samples=100, seed=5)
         if pop:
@@ -212,6 +215,7 @@ def test_kld_stop_rule_on_device_matches_oracle(engine, orc, cloud, n, pop):
     finally:
         engine.set_option(hpf.OPT_CDF_SERIAL, 0)
         engine.set_option(hpf.OPT_KLD_DEVICE_MIN, 8192)
+        engine.set_option(hpf.OPT_KLD_PERSISTENT, 0)
 
 
 def test_stop_beyond_the_first_window_takes_sized_follow_up_windows(engine, orc):
