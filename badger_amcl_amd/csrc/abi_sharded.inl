@@ -178,10 +178,10 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
     int rcb = ensure_cdf_buffers(e, n);
     if (rcb != BPF_OK)
       return rcb;
-    if (e->d_tile_flags.cap < (size_t)BPF_RED_BLOCK)
+    if (e->d_tile_slots.cap < (size_t)2 * BPF_RED_BLOCK)
     {
-      HIPCHK(e, e->d_tile_flags.reserve((size_t)BPF_RED_BLOCK));
-      HIPCHK(e, hipMemsetAsync(e->d_tile_flags.p, 0, BPF_RED_BLOCK * sizeof(unsigned), e->stream));
+      HIPCHK(e, e->d_tile_slots.reserve((size_t)2 * BPF_RED_BLOCK));
+      HIPCHK(e, hipMemsetAsync(e->d_tile_slots.p, 0xFF, 2 * BPF_RED_BLOCK * sizeof(unsigned long long), e->stream));
       e->tile_generation = 0;
     }
     HIPCHK(e, e->d_cdf_coarse.reserve((size_t)kFusedCoarse + 2));
@@ -193,11 +193,8 @@ int bpf_shard_normalize_dev(bpf_engine* e, const void* totals_dev, int world, in
     G.n.sc = e->d_scalars.p;
     G.n.alpha_slow = e->alpha_slow;
     G.n.alpha_fast = e->alpha_fast;
-    G.n.tile_sums = e->d_tile_sums.p;
-    G.n.tile_flags = e->d_tile_flags.p;
-    G.n.generation = ++e->tile_generation;
-    if (G.n.generation == 0)  // wrapped: 0 is the cleared state of the flags
-      G.n.generation = ++e->tile_generation;
+    G.n.tile_slots = e->d_tile_slots.p;
+    G.n.generation = ++e->tile_generation;  // (only its parity matters)
     G.n.cdf = e->d_cdf.p;
     G.n.coarse = e->d_cdf_coarse.p;
     G.n.coarse_shift = fused_coarse_shift(n);
@@ -435,43 +432,34 @@ int shard_stop_block(bpf_engine* e, const long long* window, int stride, int cou
     hipLaunchKernelGGL(k_shard_stop_block, dim3(1), dim3(1024), kFusedLds, e->stream, A);
   }
   HIPCHK(e, hipGetLastError());
-  const auto t0 = std::chrono::steady_clock::now();
+  int r5[5] = { 0, 0, 0, 0, 0 };
   bool seen = false;
-  for (unsigned spins = 0; !seen; ++spins)
-  {
-    seen = __atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) == A.generation;
-    if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
-      break;
-    if (!seen)
-      __builtin_ia32_pause();
-  }
+  int rcw = fused_result_wait(e, A.generation, 50, r5, &seen);
+  if (rcw != BPF_OK)
+    return rcw;
   if (!seen)
-  {
-    HIPCHK(e, hipStreamSynchronize(e->stream));  // (a mailbox wait may be running up to its bound)
-    if (__atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) != A.generation)
-      return e->fail(BPF_ERR_HIP, "k_shard_stop_block did not publish its result");
-  }
+    return e->fail(BPF_ERR_HIP, "k_shard_stop_block did not publish its result");
   if (int rcx = mailbox_check(e))
     return rcx;
-  const int* res = e->h_fused.p;
-  *status = res[4];
+  const int* res = e->h_fused.p;  // (the debug stamps, [8 ..])
+  *status = r5[3];
   if (A.debug)
     fprintf(stderr, "[shard stop block] count %d M %d leaf %d bins %d status %d levels %d (10 ns ticks): wait %d load %d "
-            "dedup %d tree %d scan %d tail %d\n", count, res[1], res[2], res[3], res[4], res[5], res[9] - res[8],
+            "dedup %d tree %d scan %d tail %d\n", count, r5[0], r5[1], r5[2], r5[3], r5[4], res[9] - res[8],
             res[11] - res[9], res[12] - res[11], res[13] - res[12], res[14] - res[13], res[15] - res[14]);
-  if (res[4] != BPF_FUSED_OK)
+  if (r5[3] != BPF_FUSED_OK)
     return BPF_OK;
-  const int M = res[1], W = A.world;
+  const int M = r5[0], W = A.world;
   const int lo = (int)(((long long)M * A.rank) / W), hi = (int)(((long long)M * (A.rank + 1)) / W);
   if (hi - lo > e->max_samples)
     return e->fail(BPF_ERR_CAPACITY, "adopted shard larger than max_samples");
   *M_out = M;
-  *leaf_out = res[2];
-  *bins_out = res[3];
+  *leaf_out = r5[1];
+  *bins_out = r5[2];
   e->cur ^= 1;
   e->sample_count = hi - lo;
-  e->leaf_count = res[2];
-  e->bin_count = res[3];
+  e->leaf_count = r5[1];
+  e->bin_count = r5[2];
   e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   e->converged_pending = true;
   e->conv_n = M;

@@ -235,12 +235,13 @@ struct bpf_engine
   int fused_partials = 0;     // > 0: the last scoring launch left that many per-block weight partials
   int tile_sums_n = -1;       // >= 0: d_tile_sums holds the 2048-tile sums of the current weights for that n
   int cdf_ready_n = -1;       // >= 0: d_cdf (and the guide) already hold the CDF of the current weights (k_normalize_cdf)
-  DevBuf<unsigned> d_tile_flags;
+  DevBuf<unsigned long long> d_tile_slots;  // k_normalize_cdf's look-back slots, [2][256]
   unsigned tile_generation = 0;
   bool fused_resample = true; // BPF_OPT_FUSED_RESAMPLE
   bool fused_lds_attr_set = false;
   bool shard_stop_attr_set = false;
   bool kld_persistent = false;         // BPF_OPT_KLD_PERSISTENT: the device tree in one launch when its grid is resident
+  int kld_generation = 0;
   int kld_persist_blocks_per_cu = -1;  // occupancy of k_kld_tree_persistent (-1: not asked yet)
   DevBuf<unsigned> d_kld_bar;
   bool shard_cdf_valid = false;        // k_normalize_gathered_cdf left the local CDF of the current weights behind

@@ -46,10 +46,10 @@ int launch_normalize_cdf(bpf_engine* e, double* w, int n)
   int rc = ensure_cdf_buffers(e, n);
   if (rc != BPF_OK)
     return rc;
-  if (e->d_tile_flags.cap < (size_t)BPF_RED_BLOCK)
+  if (e->d_tile_slots.cap < (size_t)2 * BPF_RED_BLOCK)
   {
-    HIPCHK(e, e->d_tile_flags.reserve((size_t)BPF_RED_BLOCK));
-    HIPCHK(e, hipMemsetAsync(e->d_tile_flags.p, 0, BPF_RED_BLOCK * sizeof(unsigned), e->stream));
+    HIPCHK(e, e->d_tile_slots.reserve((size_t)2 * BPF_RED_BLOCK));
+    HIPCHK(e, hipMemsetAsync(e->d_tile_slots.p, 0xFF, 2 * BPF_RED_BLOCK * sizeof(unsigned long long), e->stream));
     e->tile_generation = 0;
   }
   NormCdfArgs A{};
@@ -60,11 +60,8 @@ int launch_normalize_cdf(bpf_engine* e, double* w, int n)
   A.sc = e->d_scalars.p;
   A.alpha_slow = e->alpha_slow;
   A.alpha_fast = e->alpha_fast;
-  A.tile_sums = e->d_tile_sums.p;
-  A.tile_flags = e->d_tile_flags.p;
-  A.generation = ++e->tile_generation;
-  if (A.generation == 0)  // wrapped: 0 is the cleared state of the flags
-    A.generation = ++e->tile_generation;
+  A.tile_slots = e->d_tile_slots.p;
+  A.generation = ++e->tile_generation;  // (only its parity matters)
   A.cdf = e->d_cdf.p;
   A.coarse_shift = fused_coarse_shift(n);
   HIPCHK(e, e->d_cdf_coarse.reserve((size_t)kFusedCoarse + 2));
@@ -258,6 +255,45 @@ int ensure_limit_table(bpf_engine* e, int upto)
 // The whole resample for a candidate stream of at most kFusedWindow draws as one single-block launch
 // (k_resample_block): draws, histogram tree and KLD stop, weights 1/M, updateConverged.  *handled = false when the
 // stop lies beyond the window, a key does not fit the packing or the tree is too deep: the caller runs the general path.
+// Waits for a window kernel's three result words (fused_publish in kernels_fused.hpp) of `generation` in e->h_fused;
+// res[0..4] = M, leaf count, bin count, status, levels.  BPF_OK with *seen = false when they do not show up.
+int fused_result_wait(bpf_engine* e, int generation, int spin_ms, int res[5], bool* seen)
+{
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(e->h_fused.p);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto there = [&]() {
+    for (int k = 0; k < 3; ++k)
+      if ((unsigned)(__atomic_load_n(&w[k], __ATOMIC_ACQUIRE) >> 32) != (unsigned)generation)
+        return false;
+    return true;
+  };
+  *seen = false;
+  for (unsigned spins = 0; !*seen; ++spins)
+  {
+    *seen = there();
+    if (!*seen && (spins & 1023) == 1023 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(spin_ms))
+      break;
+    if (!*seen)
+      __builtin_ia32_pause();
+  }
+  if (!*seen)
+  {
+    HIPCHK(e, hipStreamSynchronize(e->stream));  // (a mailbox wait may be running up to its bound)
+    *seen = there();
+  }
+  if (*seen)
+  {
+    const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2];
+    res[0] = (int)(unsigned)w0;
+    res[1] = (int)((w1 >> 16) & 0xFFFF);
+    res[2] = (int)(w1 & 0xFFFF);
+    res[3] = (int)((w2 >> 8) & 0xFF);
+    res[4] = (int)(w2 & 0xFF);
+  }
+  return BPF_OK;
+}
+
 int resample_block(bpf_engine* e, int window, bool systematic, const double* targets, bool* handled)
 {
   *handled = false;
@@ -330,37 +366,28 @@ int resample_block(bpf_engine* e, int window, bool systematic, const double* tar
                        e->stream, A);
   }
   HIPCHK(e, hipGetLastError());
-  // the block publishes its generation in pinned memory when the results are there (a ~25 us kernel)
-  const auto t0 = std::chrono::steady_clock::now();
+  // the block publishes its result words in pinned memory (a ~25 us kernel)
+  int r5[5] = { 0, 0, 0, 0, 0 };
   bool seen = false;
-  for (unsigned spins = 0; !seen; ++spins)
-  {
-    seen = __atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) == A.generation;
-    if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
-      break;
-    if (!seen)
-      __builtin_ia32_pause();
-  }
+  int rcw = fused_result_wait(e, A.generation, 50, r5, &seen);
+  if (rcw != BPF_OK)
+    return rcw;
   if (!seen)
-  {
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (__atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) != A.generation)
-      return e->fail(BPF_ERR_HIP, "k_resample_block did not publish its result");
-  }
-  const int* res = e->h_fused.p;
+    return e->fail(BPF_ERR_HIP, "k_resample_block did not publish its result");
+  const int* res = e->h_fused.p;  // (the debug stamps, [6] and [8 ..])
   if (getenv("BPF_DEBUG"))
   {
     fprintf(stderr, "[resample block] window %d M %d leaf %d bins %d status %d levels %d; last block (10 ns ticks): load %d "
-            "dedup %d tree %d scan %d tail %d = %d shader clocks\n", window, res[1], res[2], res[3], res[4], res[5],
+            "dedup %d tree %d scan %d tail %d = %d shader clocks\n", window, r5[0], r5[1], r5[2], r5[3], r5[4],
             res[11] - res[9], res[12] - res[11], res[13] - res[12], res[14] - res[13], res[15] - res[14], res[6]);
     fprintf(stderr, "   block 0 draw phase (if it was not the last block): stage %d search %d gather+key %d fence %d\n",
             res[28] - res[20], res[29] - res[28], res[30] - res[29], res[31] - res[30]);
   }
-  if (res[4] != BPF_FUSED_OK)
+  if (r5[3] != BPF_FUSED_OK)
     return BPF_OK;
-  e->sample_count = res[1];
-  e->kld_leaf = res[2];
-  e->kld_bins = res[3];
+  e->sample_count = r5[0];
+  e->kld_leaf = r5[1];
+  e->kld_bins = r5[2];
   e->kld_device_used = true;
   e->fused_used = 1;
   e->resample_windows = 1;
@@ -438,7 +465,6 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
     {
       HIPCHK(e, e->d_kld_bar.reserve(4));
       HIPCHK(e, e->d_kld_tiles.reserve((size_t)std::max(pgrid, tiles)));
-      HIPCHK(e, e->h_fused.reserve(32));
       HIPCHK(e, hipMemsetAsync(e->d_kld_bar.p, 0, 4 * sizeof(unsigned), e->stream));
       KldPersistArgs P{};
       P.K = K;
@@ -448,16 +474,17 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
       P.max_levels = kMaxLevels;
       P.whole_stream = whole_stream ? 1 : 0;
       P.timeout_ticks = 2000000ll;  // 20 ms per barrier: a resident grid passes one in microseconds
-      P.result_host = e->h_fused.p;
-      e->fused_generation = (e->fused_generation % 0x3fffffff) + 1;
-      P.generation = e->fused_generation;
+      P.result_host = e->h_kld.p;
+      e->kld_generation = (e->kld_generation % 0x3fffffff) + 1;
+      P.generation = e->kld_generation;
+      e->h_kld.p[0] = 0;  // (the level-per-launch form copies its flag words here)
       hipLaunchKernelGGL(k_kld_tree_persistent, dim3(pgrid), dim3(kKldBlock), 0, e->stream, P);
       HIPCHK(e, hipGetLastError());
       const auto t0 = std::chrono::steady_clock::now();
       bool seen = false;
       for (unsigned spins = 0; !seen; ++spins)
       {
-        seen = __atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) == P.generation;
+        seen = __atomic_load_n(e->h_kld.p, __ATOMIC_ACQUIRE) == P.generation;
         if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
           break;
         if (!seen)
@@ -466,10 +493,10 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
       if (!seen)
       {
         HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (__atomic_load_n(e->h_fused.p, __ATOMIC_ACQUIRE) != P.generation)
+        if (__atomic_load_n(e->h_kld.p, __ATOMIC_ACQUIRE) != P.generation)
           return e->fail(BPF_ERR_HIP, "k_kld_tree_persistent did not publish its result");
       }
-      const int* res = e->h_fused.p;
+      const int* res = e->h_kld.p;
       if (getenv("BPF_DEBUG"))
         fprintf(stderr, "[kld persistent] n %d blocks %d stop %d leaf %d bins %d status %d levels %d\n", n, pgrid, res[1],
                 res[2], res[3], res[4], res[5]);

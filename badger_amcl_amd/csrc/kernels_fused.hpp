@@ -28,8 +28,11 @@ struct NormCdfArgs
   int n_partials;
   FilterScalars* sc;
   double alpha_slow, alpha_fast;
-  double* tile_sums;     // [tiles] normalised-weight sum per 2048-tile
-  unsigned* tile_flags;  // [tiles] generation of the sum stored there
+  // look-back slots: [2][256] tile sums as bit patterns, all-ones = "not there yet".  A launch publishes into the
+  // half `generation & 1` and block 0 puts the other half back to all-ones for the next launch, so the value is its own
+  // flag: one relaxed atomic store per tile, relaxed loads on the waiting side, no fence (an agent-scope release after a
+  // tile's 16 KB of stores is an L2 write-back of ~6 us, an acquire in a spin loop an L1 invalidate per iteration)
+  unsigned long long* tile_slots;
   unsigned generation;
   double* cdf;           // [n + 1]
   double* coarse;        // [((n - 1) >> coarse_shift) + 2]: c[min(k << coarse_shift, n)], what k_resample_block stages
@@ -37,6 +40,15 @@ struct NormCdfArgs
   int* guide;            // CDF guide table (kCdfGuide + 2)
   int* zero_word;        // the CDF-miss flag of the draw kernels that follow
 };
+
+// block 0 empties the look-back half the NEXT launch publishes into (first thing in the kernel: also on a path that
+// leaves early)
+__device__ __forceinline__ void reset_next_lookback_half(const NormCdfArgs& A)
+{
+  if (blockIdx.x == 0)
+    __hip_atomic_store(&A.tile_slots[(size_t)((A.generation & 1u) ^ 1u) * BPF_RED_BLOCK + threadIdx.x], ~0ull,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // The tile of block b: normalise (w / total, or `uniform` when the total is not positive), publish the tile's sum, wait
 // for the tiles before it and write the tile's slice of the CDF (+ subsample, + guide).  Summation shapes of
@@ -62,17 +74,21 @@ __device__ __forceinline__ void normalize_tile_and_cdf(const NormCdfArgs& A, dou
     v[k] = run;
   }
   const double tile = block_sum_256(tsum, s_wave);
+  unsigned long long* slots = A.tile_slots + (size_t)(A.generation & 1u) * BPF_RED_BLOCK;
   if (tid == 0)
   {
-    __hip_atomic_store(&A.tile_sums[b], tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&A.tile_flags[b], A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long bits = (unsigned long long)__double_as_longlong(tile);
+    if (tile != tile)
+      bits = 0x7FF8000000000000ull;  // a NaN sum (NaN weights) must not look like the empty slot
+    __hip_atomic_store(&slots[b], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- the tiles before this one (blocks are dispatched in index order: they are resident or done)
   if (tid < b)
   {
-    while (__hip_atomic_load(&A.tile_flags[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != A.generation)
+    unsigned long long v;
+    while ((v = __hip_atomic_load(&slots[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull)
       __builtin_amdgcn_s_sleep(1);
-    s_tiles[tid] = __hip_atomic_load(&A.tile_sums[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tiles[tid] = __longlong_as_double((long long)v);
   }
   __syncthreads();
   if (tid == 0)
@@ -154,6 +170,7 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfAr
   __shared__ double s_tiles[BPF_RED_BLOCK];
   __shared__ double s_tile_off;
   const int tid = threadIdx.x, b = blockIdx.x;
+  reset_next_lookback_half(A);
   // ---- the total: every block folds the partials with the same fixed tree (k_normalize_fused)
   double acc = 0.0;
   for (int i = tid; i < A.n_partials; i += BPF_RED_BLOCK)
@@ -194,6 +211,7 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered_cdf(const 
   __shared__ double s_tile_off;
   const NormCdfArgs& A = G.n;
   const int tid = threadIdx.x, b = blockIdx.x;
+  reset_next_lookback_half(A);
   if (A.n_partials > 0 && b == 0)
   {
     double acc = 0.0;
@@ -268,7 +286,7 @@ struct ResampleBlockArgs
   double thr;         // updateConverged's distance threshold
   FilterScalars* sc;
   int* conv_count;
-  volatile int* result_host;  // pinned: [1] M, [2] leaf count, [3] bin count, [4] status, [5] levels, then [0] generation
+  volatile int* result_host;  // pinned: three result words (fused_publish)
   int generation;
   int debug;          // also copy the phase clocks out ([6], [8 ..])
 };
@@ -443,6 +461,23 @@ __device__ __forceinline__ void fused_stop_init(FusedStatics& S, const FusedLdsM
     S.count = 0;
     S.levels = 0;
   }
+}
+
+// The result of a window kernel for the host, in pinned memory: three 64-bit words that each carry the launch's
+// generation in their high half -- (gen | M), (gen | leaf count << 16 | bin count), (gen | status << 8 | levels) --
+// so the host takes them when all three show the generation it waits for and the kernel needs no fence in front of a
+// flag word (a system-scope release is a write-back of everything the block has just stored: ~5 us behind the 16 KB of
+// weights; the host reads none of that).
+__device__ __forceinline__ void fused_publish(volatile int* result_host, int generation, int M, int leaf, int bins,
+                                              int status, int levels)
+{
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(const_cast<int*>(result_host));
+  const unsigned long long g = (unsigned long long)(unsigned)generation << 32;
+  __hip_atomic_store(&out[0], g | (unsigned)M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&out[1], g | ((unsigned)(leaf & 0xFFFF) << 16) | (unsigned)(bins & 0xFFFF), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&out[2], g | ((unsigned)(status & 0xFF) << 8) | (unsigned)(levels & 0xFF), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The stop rule over the window's draws, for the block that holds all of them (keys in L.key, thread t owns draws
@@ -759,25 +794,31 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
   {
     const int i = i_sel;
     const double x = A.src.x[i], y = A.src.y[i], th = A.src.th[i];
-    A.dst.x[m_draw] = x;
-    A.dst.y[m_draw] = y;
+    // What the last block reads back (x, y, key) is stored write-through (agent-scope atomic stores: sc1) and read
+    // there with agent-scope loads, so the hand-off needs no release / acquire fence, only every storing wave's
+    // drain in front of the block's ticket (cdna_hip_programming.md, Guideline 16 form R1; fences by all 1 024
+    // threads here took 2.8 us, and an acquire in the last block 1.5).  theta is not read in this launch.
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&A.dst.x[m_draw]),
+                       (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&A.dst.y[m_draw]),
+                       (unsigned long long)__double_as_longlong(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A.dst.th[m_draw] = th;
     int key[3];
     pose_key(x, y, th, key);
     unsigned long long pk1;
     if (!kld_pack(key, &pk1))
       pk1 = kKldEmpty;  // reported by the tree phase
-    A.keys[m_draw] = pk1;
+    __hip_atomic_store(&A.keys[m_draw], pk1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (stamps)
       BPF_FUSED_STAMP(10);
   }
-  __threadfence();
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores ...
+  __syncthreads();                                    // ... before the block takes its ticket
   if (stamps)
     BPF_FUSED_STAMP(11);
   if (tid == 0)
   {
-    const unsigned prev = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     S.last = prev == gridDim.x - 1;
     if (S.last)
       __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -793,7 +834,7 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
     }
     return;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the loads below the ticket)
   BPF_FUSED_STAMP(1);
   const long long shader_clk0 = clock64();
 
@@ -890,14 +931,9 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
       out[6] = (int)(clock64() - shader_clk0);
       for (int k = 0; k < 12; ++k)
         out[8 + k] = S.stamp[k];
+      __threadfence_system();
     }
-    out[1] = M;
-    out[2] = S.leaf;
-    out[3] = S.bins;
-    out[4] = status;
-    out[5] = S.levels;
-    __threadfence_system();
-    __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);
   }
 }
 
@@ -924,7 +960,7 @@ struct ShardStopArgs
   MailboxDev mb;            // world 0: nothing to wait for
   int wait_parity;
   unsigned long long wait_gen;
-  volatile int* result_host;  // pinned: [1] M, [2] leaf count, [3] bin count, [4] status, [5] levels, then [0] generation
+  volatile int* result_host;  // pinned: three result words (fused_publish)
   int generation;
   int debug;
 };
@@ -943,11 +979,7 @@ __global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A
   if (A.mb.world > 0 && !mb_block_wait(A.mb, mb_win_done(A.mb.peer[A.mb.rank], A.wait_parity, 0), A.wait_gen, 1))
   {
     if (tid == 0)
-    {
-      out[4] = BPF_FUSED_EXCHANGE;
-      __threadfence_system();
-      __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+      fused_publish(out, A.generation, 0, 0, 0, BPF_FUSED_EXCHANGE, 0);
     return;
   }
   BPF_FUSED_STAMP(1);
@@ -1068,15 +1100,12 @@ __global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A
   if (tid == 0)
   {
     if (A.debug)
+    {
       for (int k = 0; k < 8; ++k)
         out[8 + k] = S.stamp[k];
-    out[1] = M;
-    out[2] = S.leaf;
-    out[3] = S.bins;
-    out[4] = status;
-    out[5] = S.levels;
-    __threadfence_system();
-    __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+    fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);
   }
 }
 

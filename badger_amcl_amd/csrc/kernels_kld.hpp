@@ -378,12 +378,14 @@ __device__ __forceinline__ int kld_ld(const int* p)
 
 __device__ __forceinline__ bool kld_grid_sync(const KldPersistArgs& P, unsigned& epoch, int* s_flag)
 {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's atomics and stores are out
   __syncthreads();
   if (threadIdx.x == 0)
   {
     ++epoch;
     int ok = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned prev = __hip_atomic_fetch_add(&P.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == gridDim.x - 1)
     {

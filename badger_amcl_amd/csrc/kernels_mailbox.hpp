@@ -70,11 +70,15 @@ __device__ __forceinline__ long long* mb_window(char* base, int parity, long lon
 // bounded spin until *slot >= gen; false when the time ran out (every wave reaches the exit either way)
 __device__ __forceinline__ bool mb_spin_ge(const unsigned long long* slot, unsigned long long gen, long long timeout_ticks)
 {
+  // relaxed polls (an acquire load is a load plus a cache invalidate, per iteration), one acquire once the word is there
   const long long t0 = wall_clock64();
   for (;;)
   {
-    if (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= gen)
+    if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= gen)
+    {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
       return true;
+    }
     if (wall_clock64() - t0 > timeout_ticks)
       return false;
     __builtin_amdgcn_s_sleep(2);
@@ -129,10 +133,14 @@ __device__ __forceinline__ void mb_post_total(const MailboxDev& M, int parity, u
 __device__ __forceinline__ void mb_window_done_when_last(const MailboxDev& M, int parity, unsigned long long gen,
                                                          unsigned* counter)
 {
-  __threadfence_system();  // this thread's peer stores have landed
+  // every storing wave drains its peer stores, then ONE system-scope release per block behind the barrier (a fence by
+  // every thread costs 2-4x one lane's)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
   {
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned prev = atomicAdd(counter, 1u);
     if (prev == gridDim.x - 1)
     {
