@@ -53,7 +53,17 @@ __device__ __forceinline__ void reset_next_lookback_half(const NormCdfArgs& A)
 // The tile of block b: normalise (w / total, or `uniform` when the total is not positive), publish the tile's sum, wait
 // for the tiles before it and write the tile's slice of the CDF (+ subsample, + guide).  Summation shapes of
 // k_normalize_fused (tile sum) and k_scan_final (running sums).
-__device__ __forceinline__ void normalize_tile_and_cdf(const NormCdfArgs& A, double total, double uniform, double* s_wave,
+// this thread's eight scored weights: asked for first thing, so that they arrive while the total is being formed
+__device__ __forceinline__ void load_tile_weights(const NormCdfArgs& A, double (&raw)[BPF_RED_PER_THREAD])
+{
+  const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+    raw[k] = (base + k < (size_t)A.n) ? A.w[base + k] : 0.0;
+}
+
+__device__ __forceinline__ void normalize_tile_and_cdf(const NormCdfArgs& A, double total, double uniform,
+                                                       const double (&raw)[BPF_RED_PER_THREAD], double* s_wave,
                                                        double* s_tiles, double* s_tile_off)
 {
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -66,7 +76,7 @@ __device__ __forceinline__ void normalize_tile_and_cdf(const NormCdfArgs& A, dou
     double x = 0.0;
     if (base + k < (size_t)A.n)
     {
-      x = (total > 0.0) ? A.w[base + k] / total : uniform;
+      x = (total > 0.0) ? raw[k] / total : uniform;
       A.w[base + k] = x;
       tsum += x;
     }
@@ -171,6 +181,8 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfAr
   __shared__ double s_tile_off;
   const int tid = threadIdx.x, b = blockIdx.x;
   reset_next_lookback_half(A);
+  double raw[BPF_RED_PER_THREAD];
+  load_tile_weights(A, raw);
   // ---- the total: every block folds the partials with the same fixed tree (k_normalize_fused)
   double acc = 0.0;
   for (int i = tid; i < A.n_partials; i += BPF_RED_BLOCK)
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_cdf(const NormCdfAr
     update_weight_averages(sc, total, A.n, A.alpha_slow, A.alpha_fast);
     *A.zero_word = 0;
   }
-  normalize_tile_and_cdf(A, total, 1.0 / A.n, s_wave, s_tiles, &s_tile_off);
+  normalize_tile_and_cdf(A, total, 1.0 / A.n, raw, s_wave, s_tiles, &s_tile_off);
 }
 
 // Sharded filter, mailbox mode (k_normalize_gathered + the CDF): block 0 folds the scoring kernel's partials into the
@@ -212,6 +224,8 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered_cdf(const 
   const NormCdfArgs& A = G.n;
   const int tid = threadIdx.x, b = blockIdx.x;
   reset_next_lookback_half(A);
+  double raw[BPF_RED_PER_THREAD];
+  load_tile_weights(A, raw);  // (the weights are final since the scoring launch; the wait below is for the totals)
   if (A.n_partials > 0 && b == 0)
   {
     double acc = 0.0;
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_gathered_cdf(const 
     if (G.zero_word2 != nullptr)
       *G.zero_word2 = 0;
   }
-  normalize_tile_and_cdf(A, total, 1.0 / G.global_n, s_wave, s_tiles, &s_tile_off);
+  normalize_tile_and_cdf(A, total, 1.0 / G.global_n, raw, s_wave, s_tiles, &s_tile_off);
   if (G.sum_out != nullptr && b == (int)gridDim.x - 1 && tid == (A.n - 1 - b * BPF_RED_TILE) / BPF_RED_PER_THREAD)
     *G.sum_out = A.cdf[A.n];  // (this thread wrote it)
 }
@@ -839,29 +853,33 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
   const long long shader_clk0 = clock64();
 
   // ================================================================== the last block: every draw of the window
-  fused_stop_init(S, L, A.window, A.systematic, A.limit);
-  // thread t owns draws m = 4t .. 4t + 3 from here on
+  // thread t owns draws m = 4t .. 4t + 3 from here on; their loads are in flight while the tables are cleared
   const int m_base = tid * Q;
   bool act[Q];
   unsigned long long pk[Q];
+  double lx[Q], ly[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+  {
+    const int m = m_base + q;
+    act[q] = m < A.window;
+    pk[q] = act[q] ? __hip_atomic_load(&A.keys[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kKldEmpty;
+    lx[q] = act[q] ? __hip_atomic_load(&A.dst.x[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    ly[q] = act[q] ? __hip_atomic_load(&A.dst.y[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  }
+  fused_stop_init(S, L, A.window, A.systematic, A.limit);
   {
     bool bad_key = false;
 #pragma unroll
     for (int q = 0; q < Q; ++q)
-    {
-      const int m = m_base + q;
-      act[q] = m < A.window;
-      pk[q] = act[q] ? __hip_atomic_load(&A.keys[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kKldEmpty;
-      const double x = act[q] ? __hip_atomic_load(&A.dst.x[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      const double y = act[q] ? __hip_atomic_load(&A.dst.y[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       if (act[q])
       {
+        const int m = m_base + q;
         bad_key |= pk[q] == kKldEmpty;
         L.key[m] = pk[q];
-        L.x[m] = x;
-        L.y[m] = y;
+        L.x[m] = lx[q];
+        L.y[m] = ly[q];
       }
-    }
     __syncthreads();  // S.bad = 0 is in place
     if (bad_key)
       S.bad = BPF_FUSED_KEY_RANGE;

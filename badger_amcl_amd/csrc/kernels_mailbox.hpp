@@ -77,6 +77,7 @@ __device__ __forceinline__ bool mb_spin_ge(const unsigned long long* slot, unsig
     if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= gen)
     {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed when the caller's barrier opens
       return true;
     }
     if (wall_clock64() - t0 > timeout_ticks)
@@ -113,7 +114,9 @@ __device__ __forceinline__ bool mb_block_wait(const MailboxDev& M, unsigned long
       __hip_atomic_store(M.dev_error + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // what the peers wrote before their words is visible to every thread
+  // The polling lanes (one wave) have acquired at system scope and drained before the barrier above: that covers the
+  // block's CU.  What the peers wrote sits in this rank's uncached mailbox, which no cache holds anyway.
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   return ok != 0;
 }
 
