@@ -129,7 +129,7 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
     if (rc != BPF_OK)
       return rc;
   }
-  HIPCHK(e, hipStreamSynchronize(e->stream));  // h_aos staging is reused by the next call
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller's buffer is only the call's
   return BPF_OK;
 }
 

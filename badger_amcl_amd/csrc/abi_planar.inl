@@ -129,15 +129,8 @@ double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int 
   rc = sum_into_slot(e, e->scratch.w.p, sample_count, 0, 0, sample_count);
   if (rc != BPF_OK)
     return bail(rc);
-  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(sample_count, 256)), dim3(256), 0, e->stream, e->scratch.dev(),
-                     e->d_aos.p, sample_count);
-  if (hipMemcpyAsync(e->h_aos.p, e->d_aos.p, (size_t)sample_count * sizeof(double4), hipMemcpyDeviceToHost,
-                     e->stream) != hipSuccess ||
-      hipMemcpyAsync(e->h_scalars.p, e->d_scalars.p, sizeof(FilterScalars), hipMemcpyDeviceToHost, e->stream) !=
-          hipSuccess ||
-      hipStreamSynchronize(e->stream) != hipSuccess)
-    return bail(e->fail(BPF_ERR_HIP, "copy back"));
-  for (int i = 0; i < sample_count; ++i)
-    samples[4 * i + 3] = e->h_aos.p[i].w;
+  rc = download_weights(e, e->scratch, sample_count, samples);
+  if (rc != BPF_OK)
+    return bail(rc);
   return e->h_scalars.p->v[0];
 }

@@ -878,12 +878,26 @@ int resample_systematic(bpf_engine* e, double w_diff)
 
 int upload_samples(bpf_engine* e, const double* aos, int n, SampleSet& dst)
 {
-  HIPCHK(e, e->h_aos.reserve((size_t)n));
   HIPCHK(e, e->d_aos.reserve((size_t)n));
   HIPCHK(e, dst.reserve((size_t)n));
-  std::memcpy(e->h_aos.p, aos, (size_t)n * sizeof(double4));
-  HIPCHK(e, hipMemcpyAsync(e->d_aos.p, e->h_aos.p, (size_t)n * sizeof(double4), hipMemcpyHostToDevice, e->stream));
+  // the caller's (pageable) buffer straight to the runtime, which pipelines its own bounce buffers: a staging memcpy of
+  // the whole set on this thread followed by one DMA serialises the two (0.37 against 0.31 ms per update at 100 k)
+  HIPCHK(e, hipMemcpyAsync(e->d_aos.p, aos, (size_t)n * sizeof(double4), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->d_aos.p, dst.dev(), n);
   HIPCHK(e, hipGetLastError());
+  return BPF_OK;
+}
+
+// the weights of a device-side set back into the caller's AoS records (only the weight of a record changes in a
+// sensor update): 8 bytes per particle over PCIe instead of 32, no re-interleaving launch
+int download_weights(bpf_engine* e, const SampleSet& src, int n, double* aos)
+{
+  HIPCHK(e, e->h_aos.reserve((size_t)n));
+  double* hw = reinterpret_cast<double*>(e->h_aos.p);
+  HIPCHK(e, hipMemcpyAsync(hw, src.w.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->h_scalars.p, e->d_scalars.p, sizeof(FilterScalars), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; ++i)
+    aos[4 * (size_t)i + 3] = hw[i];
   return BPF_OK;
 }

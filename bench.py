@@ -497,7 +497,7 @@ def main():
                 sc.applyModelToSampleSet(data, host_samples, 0)
             dth = (time.perf_counter() - t0h) / 10
             host_path = {"ms_per_update": dth * 1e3, "evals_per_s": float(wl["n"]) * wl["beams"] / dth,
-                         "what": "applyModelToSampleSet with host buffers: 3.2 MB H2D + scoring + 3.2 MB D2H per call"}
+                         "what": "applyModelToSampleSet with host buffers: 3.2 MB H2D + scoring + 0.8 MB D2H (the weights) per call"}
             # the whole cycle with the set crossing PCIe both ways (SURVEY 8(d)'s end-to-end figure): H2D of the set
             # (32 B/particle), sensor update, resample, D2H of the resampled set -- never `value` either
             pf.initWithSamples(wl["samples"])
