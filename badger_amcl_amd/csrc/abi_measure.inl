@@ -54,6 +54,7 @@ int bpf_profile_reset(bpf_engine* e)
     return BPF_ERR_INVALID_ARGUMENT;
   int rc = drain_events(e);
   std::memset(&e->prof, 0, sizeof(e->prof));
+  e->timed_launches = 0;  // the first scoring launch after a reset is a timed one
   return rc;
 }
 

@@ -24,8 +24,8 @@ struct ProfScope
 // kernel's own start-to-end, without the marker packets and launch gap that hipEventRecord around a launch adds
 // (~3.5 us), and agrees with the rocprofv3 kernel trace.  A timed dispatch costs the step ~5 us (completion signal
 // with timestamps), so in mode 1 (scoring kernels only, used inside bench.py's timed region) every
-// kTimedLaunchStride-th launch is timed; mode 2 times all.  Falls back to a plain launch when profiling is off.
-constexpr unsigned kTimedLaunchStride = 4;
+// kTimedLaunchStride-th launch is timed, starting with the first after bpf_profile_reset; mode 2 times all.  Falls back to a plain launch when profiling is off.
+constexpr unsigned kTimedLaunchStride = 8;
 #define LAUNCH_TIMED(e, klass, kernel, grid, block, lds, ...)                                                         \
   do                                                                                                                  \
   {                                                                                                                   \
