@@ -323,8 +323,24 @@ int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m
     if (rcf != BPF_OK)
       return rcf;
   }
+  if (!e->shard_chain && m0 < kFusedWindow)
+  {
+    int rcj = ensure_fused_jump(e);
+    if (rcj != BPF_OK)
+      return rcj;
+    A.jump_table = e->d_fused_jump.p;
+    A.jump_table_n = kFusedWindow;
+  }
+  size_t lds = 0;
+  if (e->cdf_coarse_n == A.n_src && A.n_src > 0 && m1 - m0 <= 2 * kFusedWindow)
+  {
+    // a short window after k_normalize_gathered_cdf: the draws bracket themselves in the CDF subsample first
+    A.coarse = e->d_cdf_coarse.p;
+    A.coarse_shift = fused_coarse_shift(A.n_src);
+    lds = ((size_t)((A.n_src - 1) >> A.coarse_shift) + 2) * sizeof(double);
+  }
   ProfScope ps(e, BPF_K_DRAW);
-  hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(m1 - m0, 256)), dim3(256), 0, e->stream, A);
+  hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(m1 - m0, 256)), dim3(256), lds, e->stream, A);
   HIPCHK(e, hipGetLastError());
   return BPF_OK;
 }
@@ -715,8 +731,15 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
   if (rcm != BPF_OK)
     return rcm;
   {
+    size_t lds = 0;
+    if (e->cdf_coarse_n == A.n_src && A.n_src > 0 && count <= 2 * kFusedWindow)
+    {
+      A.coarse = e->d_cdf_coarse.p;
+      A.coarse_shift = fused_coarse_shift(A.n_src);
+      lds = ((size_t)((A.n_src - 1) >> A.coarse_shift) + 2) * sizeof(double);
+    }
     ProfScope ps(e, BPF_K_DRAW);
-    hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(count, 256)), dim3(256), 0, e->stream, A);
+    hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(count, 256)), dim3(256), lds, e->stream, A);
   }
   HIPCHK(e, hipGetLastError());
   if (!e->targets_read)

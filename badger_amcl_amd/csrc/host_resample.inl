@@ -255,6 +255,34 @@ int ensure_limit_table(bpf_engine* e, int upto)
 // The whole resample for a candidate stream of at most kFusedWindow draws as one single-block launch
 // (k_resample_block): draws, histogram tree and KLD stop, weights 1/M, updateConverged.  *handled = false when the
 // stop lies beyond the window, a key does not fit the packing or the tree is too deep: the caller runs the general path.
+// draw m takes stream element 2 m + 2: the composed LCG step for that distance, per draw of a window kernel
+int ensure_fused_jump(bpf_engine* e)
+{
+  if (e->d_fused_jump.p)
+    return BPF_OK;
+  std::vector<FusedJump> jt(kFusedWindow);
+  const uint64_t mask = (1ull << 48) - 1;
+  for (int m = 0; m < kFusedWindow; ++m)
+  {
+    uint64_t a = 1, c = 0, k = 2ull * (uint64_t)m + 2ull;
+    for (int j = 0; k != 0 && j < 48; ++j, k >>= 1)
+      if (k & 1)
+      {
+        a = (a * e->jump.A[j]) & mask;
+        c = (c * e->jump.A[j] + e->jump.C[j]) & mask;
+      }
+    jt[m].a = a;
+    jt[m].c = c;
+  }
+  HIPCHK(e, e->d_fused_jump.reserve(kFusedWindow));
+  HIPCHK(e, hipMemcpy(e->d_fused_jump.p, jt.data(), jt.size() * sizeof(FusedJump), hipMemcpyHostToDevice));
+  HIPCHK(e, e->d_fused_keys.reserve(kFusedWindow));
+  HIPCHK(e, e->d_fused_counter.reserve(1));
+  // on the engine's stream: a plain hipMemset may still be in flight when the first launch counts its blocks
+  HIPCHK(e, hipMemsetAsync(e->d_fused_counter.p, 0, sizeof(unsigned), e->stream));
+  return BPF_OK;
+}
+
 // Waits for a window kernel's three result words (fused_publish in kernels_fused.hpp) of `generation` in e->h_fused;
 // res[0..4] = M, leaf count, bin count, status, levels.  BPF_OK with *seen = false when they do not show up.
 int fused_result_wait(bpf_engine* e, int generation, int spin_ms, int res[5], bool* seen)
@@ -312,30 +340,9 @@ int resample_block(bpf_engine* e, int window, bool systematic, const double* tar
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
     e->fused_lds_attr_set = true;
   }
-  if (!e->d_fused_jump.p)
-  {
-    // draw m takes stream element 2 m + 2: the composed LCG step for that distance, per draw of the window
-    std::vector<FusedJump> jt(kFusedWindow);
-    const uint64_t mask = (1ull << 48) - 1;
-    for (int m = 0; m < kFusedWindow; ++m)
-    {
-      uint64_t a = 1, c = 0, k = 2ull * (uint64_t)m + 2ull;
-      for (int j = 0; k != 0 && j < 48; ++j, k >>= 1)
-        if (k & 1)
-        {
-          a = (a * e->jump.A[j]) & mask;
-          c = (c * e->jump.A[j] + e->jump.C[j]) & mask;
-        }
-      jt[m].a = a;
-      jt[m].c = c;
-    }
-    HIPCHK(e, e->d_fused_jump.reserve(kFusedWindow));
-    HIPCHK(e, hipMemcpy(e->d_fused_jump.p, jt.data(), jt.size() * sizeof(FusedJump), hipMemcpyHostToDevice));
-    HIPCHK(e, e->d_fused_keys.reserve(kFusedWindow));
-    HIPCHK(e, e->d_fused_counter.reserve(1));
-    // on the engine's stream: a plain hipMemset may still be in flight when the first launch counts its blocks
-    HIPCHK(e, hipMemsetAsync(e->d_fused_counter.p, 0, sizeof(unsigned), e->stream));
-  }
+  int rcj = ensure_fused_jump(e);
+  if (rcj != BPF_OK)
+    return rcj;
   ResampleBlockArgs A{};
   A.src = a.dev();
   A.n_src = e->sample_count;

@@ -272,11 +272,6 @@ enum
   BPF_FUSED_TOO_MANY_BINS = 4
 };
 
-struct FusedJump
-{
-  uint64_t a, c;  // x -> a * x + c (mod 2^48) advances the drand48 state by 2 m + 2 elements (draw m)
-};
-
 constexpr int kFusedDrawsPerBlock = 128;  // draw phase: the window is spread over window / 128 blocks (CUs)
 
 struct ResampleBlockArgs

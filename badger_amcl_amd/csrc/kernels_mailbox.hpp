@@ -144,12 +144,16 @@ __device__ __forceinline__ void mb_window_done_when_last(const MailboxDev& M, in
   {
     __threadfence_system();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned prev = atomicAdd(counter, 1u);
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == gridDim.x - 1)
     {
-      *counter = 0;
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // every block's peer stores were out before its ticket: ONE more system-scope fence, then the W "done" words
+      // relaxed (a release store per peer is a cache write-back per peer: 8 ranks, 8 of them in a row)
+      __threadfence_system();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (int r = 0; r < M.world; ++r)
-        __hip_atomic_store(mb_win_done(M.peer[r], parity, M.rank), gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(mb_win_done(M.peer[r], parity, M.rank), gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -822,11 +822,20 @@ __global__ void k_draw_select(const DrawArgs A)
 // r falls into its slice [offset, offset + sums[rank]) of the global CDF (the slices partition
 // [0, total) exactly because every rank forms the same left-to-right running sum of `sums`),
 // and writes pose bits + histogram key as int64 rows; draws owned by another shard are zeroed.
+struct FusedJump
+{
+  uint64_t a, c;  // x -> a * x + c (mod 2^48) advances the drand48 state by 2 m + 2 elements (draw m)
+};
+
 struct WindowArgs
 {
+  const FusedJump* jump_table;  // nullable: the composed step per draw m < jump_table_n (instead of 48 square-and-multiply rounds)
+  int jump_table_n;
   ParticlesDev src;
   int n_src;
   const double* cdf;     // local running sum, c[0] = 0
+  const double* coarse;  // nullable: c[min(k << coarse_shift, n_src)], k = 0 .. ((n_src - 1) >> shift) + 1 (k_normalize_cdf's
+  int coarse_shift;      // subsample); the block stages it in LDS and a draw brackets itself there first
   const double* sums;    // [world] per-shard CDF sums (or weight totals), rank order
   int sums_are_totals;   // 1: the shard's slice of [0,1) is total_r / sum(totals) by definition
   int rank, world;
@@ -852,24 +861,31 @@ struct WindowArgs
 };
 
 // one draw of the window: true when this shard owns column o (out[] then holds pose bits + key)
-__device__ __forceinline__ bool draw_window_column(const WindowArgs& A, int o, long long out[6])
+// Slice [offset, top) of the global CDF owned by this shard.  With CDF sums the slices tile [0, total) exactly.
+// With weight totals (one exchange less) the slice of shard q is defined as total_q / T, the same
+// quotient on every rank; the shard's own running sum is used inside it and its last particle
+// takes whatever rounding leaves between the end of that sum and the end of the slice.
+__device__ __forceinline__ void shard_slice(const double* sums, int sums_are_totals, int rank, int world,
+                                            double* offset_out, double* top_out)
 {
-  const int m = A.m0 + o;
-  // Slice of the global CDF owned by this shard.  With CDF sums the slices tile [0, total) exactly.
-  // With weight totals (one exchange less) the slice of shard q is defined as total_q / T, the same
-  // quotient on every rank; the shard's own running sum is used inside it and its last particle
-  // takes whatever rounding leaves between the end of that sum and the end of the slice.
   double T = 1.0;
-  if (A.sums_are_totals)
+  if (sums_are_totals)
   {
     T = 0.0;
-    for (int r = 0; r < A.world; ++r)
-      T += A.sums[r];
+    for (int r = 0; r < world; ++r)
+      T += sums[r];
   }
   double offset = 0.0;
-  for (int r = 0; r < A.rank; ++r)
-    offset += A.sums_are_totals ? A.sums[r] / T : A.sums[r];
-  const double top = offset + (A.sums_are_totals ? A.sums[A.rank] / T : A.sums[A.rank]);
+  for (int r = 0; r < rank; ++r)
+    offset += sums_are_totals ? sums[r] / T : sums[r];
+  *offset_out = offset;
+  *top_out = offset + (sums_are_totals ? sums[rank] / T : sums[rank]);
+}
+
+__device__ __forceinline__ bool draw_window_column(const WindowArgs& A, int o, long long out[6], double offset,
+                                                   double top, const double* s_coarse = nullptr)
+{
+  const int m = A.m0 + o;
   double r = 0.0;
   bool random = false;
   double rx = 0.0, ry = 0.0, rth = 0.0;
@@ -895,6 +911,11 @@ __device__ __forceinline__ bool draw_window_column(const WindowArgs& A, int o, l
     }
     else
       r = ldexp((double)xs, -48);
+  }
+  else if (A.jump_table != nullptr && m < A.jump_table_n)
+  {
+    const FusedJump J = A.jump_table[m];
+    r = ldexp((double)((J.a * A.rng_state + J.c) & ((1ull << 48) - 1)), -48);
   }
   else
   {
@@ -941,6 +962,22 @@ __device__ __forceinline__ bool draw_window_column(const WindowArgs& A, int o, l
     else
     {
       int lo = 0, hi = A.n_src;  // offset + c[lo] <= r < offset + c[hi]
+      if (s_coarse != nullptr)
+      {
+        // the bracket of 2^shift CDF values first, from the subsample staged in LDS: ~12 of the ~17 bisection steps
+        // without a trip to memory (same comparisons on the same values, so the same interval)
+        int kl = 0, kh = ((A.n_src - 1) >> A.coarse_shift) + 1;
+        while (kh - kl > 1)
+        {
+          const int mid = kl + ((kh - kl) >> 1);
+          if (offset + s_coarse[mid] <= r)
+            kl = mid;
+          else
+            kh = mid;
+        }
+        lo = kl << A.coarse_shift;
+        hi = min(kh << A.coarse_shift, A.n_src);
+      }
       while (hi - lo > 1)
       {
         const int mid = lo + ((hi - lo) >> 1);
@@ -964,12 +1001,34 @@ __device__ __forceinline__ bool draw_window_column(const WindowArgs& A, int o, l
   return mine;
 }
 
+// dynamic LDS: the CDF subsample when A.coarse is given ((((n_src - 1) >> shift) + 2) doubles), else none
 __global__ void k_draw_window(const WindowArgs A)
 {
+  extern __shared__ __align__(16) unsigned char draw_smem[];
+  double* s_coarse = nullptr;
+  if (A.coarse != nullptr)
+  {
+    s_coarse = reinterpret_cast<double*>(draw_smem);
+    const int n_coarse = ((A.n_src - 1) >> A.coarse_shift) + 1;
+    for (int k = threadIdx.x; k <= n_coarse; k += blockDim.x)
+      s_coarse[k] = A.coarse[k];
+    __syncthreads();
+  }
+  // the shards' sums sit in uncached mailbox memory (or come from a collective): one round of loads per block, the
+  // slice from LDS copies (same additions in the same order as every thread used to do from memory)
+  __shared__ double s_sums[kMailboxMaxWorld];
+  __shared__ double s_slice[2];
+  if ((int)threadIdx.x < A.world && A.world <= kMailboxMaxWorld)
+    s_sums[threadIdx.x] = A.sums[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    shard_slice(A.world <= kMailboxMaxWorld ? s_sums : A.sums, A.sums_are_totals, A.rank, A.world, &s_slice[0],
+                &s_slice[1]);
+  __syncthreads();
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = A.m0 + o < A.m1;
   long long out[6] = { 0, 0, 0, 0, 0, 0 };
-  const bool owned = live && draw_window_column(A, o, out);
+  const bool owned = live && draw_window_column(A, o, out, s_slice[0], s_slice[1], s_coarse);
   if (A.mb.world > 0)
   {
     if (owned)
