@@ -284,6 +284,9 @@ def workload_name(args, world):
     """config.workload: BASELINE.json's own wording where the run IS one of its configs."""
     key = (args.model, args.particles, args.beams, args.map_size)
     if key == ("lf", 100000, 1081, 2000):
+        if world > 1:
+            return ("2D likelihood-field, 100k particles per GPU, 1081 beams, 2000x2000 map: ONE filter of %d particles "
+                    "sharded over %d GPUs (configs[3]'s layout at configs[1]'s per-GPU size)" % (100000 * world, world))
         return "2D likelihood-field, 100k particles, 1081 beams, 2000x2000 map"
     if key == ("lf", 5000, 181, 400):
         return "2D likelihood-field, 5000 particles, 181-beam scan, 400x400 static map (configs[0]: the reference's CPU case)"
