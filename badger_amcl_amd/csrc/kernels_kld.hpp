@@ -257,8 +257,10 @@ __global__ __launch_bounds__(kKldBlock) void k_kld_descend(const KldArgs A, int*
     }
   }
   block_atomic_min(A.first, (unsigned)c, i, still, s_tag, s_val);
-  if (still)
-    *waiting = 1;  // every writer stores the same value
+  // keys of this block that still wait after this level (the host looks for zero; BPF_DEBUG prints the counts)
+  const int cnt = __syncthreads_count(still ? 1 : 0);
+  if (threadIdx.x == 0 && cnt > 0)
+    atomicAdd(waiting, cnt);
 }
 
 // inclusive scan of delta (int2) in tiles of 2048, three launches
@@ -408,16 +410,17 @@ struct KldPersistArgs
   int generation;
 };
 
-// Everything the blocks exchange inside the launch goes through agent-scope atomics (atomicMin into first / child,
-// atomic stores of the tile sums and level words, atomic loads on the reading side), so the barrier only has to order
-// them: the block barrier waits for every wave's outstanding memory operations, then thread 0 arrives with a release,
-// spins on the generation word and acquires.  (Fences by all 1024 threads cost ~45 us per barrier: 1 600 L2
-// write-back / invalidate requests in flight.)
+// agent-scope load: served past this CU's L1 (what another CU's atomics wrote is not in it)
 __device__ __forceinline__ int kld_ld(const int* p)
 {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Everything the blocks exchange inside the launch goes through agent-scope atomics (atomicMin into first / child,
+// atomic stores of the tile sums and level words, atomic loads on the reading side), so the barrier only has to order
+// them: the block barrier waits for every wave's outstanding memory operations, then thread 0 arrives with a release,
+// spins on the generation word and acquires.  (Fences by all 1024 threads cost ~45 us per barrier: 1 600 L2
+// write-back / invalidate requests in flight.)
 __device__ __forceinline__ bool kld_grid_sync(const KldPersistArgs& P, unsigned& epoch, int* s_flag)
 {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's atomics and stores are out
