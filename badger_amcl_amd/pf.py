@@ -177,6 +177,7 @@ class OccupancyMap:
 
     def calcRange(self, ox, oy, oa, max_range):
         """OccupancyMap::calcRange (occupancy_map.cpp:257-364), batched: arrays of origins, angles and max ranges."""
+        self.upload()  # the cells alone are enough (no distance LUT needed), as for the reference's calcRange
         ox, oy, oa = (np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (ox, oy, oa))
         mr = np.ascontiguousarray(np.broadcast_to(np.asarray(max_range, dtype=np.float64), ox.shape))
         # libm's cos / sin (what the reference calls), not numpy's vector loops, which may differ in the last bit
