@@ -95,9 +95,27 @@ __device__ __forceinline__ void normalize_tile_and_cdf(const NormCdfArgs& A, dou
   // ---- the tiles before this one (blocks are dispatched in index order: they are resident or done)
   if (tid < b)
   {
+    // bounded (every wave must reach its exit whatever happens to another block): after 50 ms the tile counts as empty
+    // and the CDF-miss word is raised, which the resample that follows reports
     unsigned long long v;
-    while ((v = __hip_atomic_load(&slots[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull)
+    long long t0 = 0;
+    for (unsigned spins = 0;
+         (v = __hip_atomic_load(&slots[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull; ++spins)
+    {
       __builtin_amdgcn_s_sleep(1);
+      if ((spins & 255u) == 255u)
+      {
+        const long long now = wall_clock64();
+        if (t0 == 0)
+          t0 = now;
+        else if (now - t0 > 5000000ll)
+        {
+          atomicExch(A.zero_word, 1);
+          v = 0ull;
+          break;
+        }
+      }
+    }
     s_tiles[tid] = __longlong_as_double((long long)v);
   }
   __syncthreads();

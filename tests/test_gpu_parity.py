@@ -111,6 +111,27 @@ def test_zero_total_resets_to_uniform(engine, orc):
     assert np.all(cur.samples[:, 3] == 1.0 / 100)
 
 
+@pytest.mark.timeout(120)
+def test_infinite_weights_do_not_stall_the_normalise_launch(engine, orc):
+    """inf / inf: the tile sums of the normalise launch are NaN.  Its blocks hand those sums to each other through
+    slots whose empty state is a NaN bit pattern as well (kernels_fused.hpp), so this is the input that must not leave
+    a block waiting: the call returns, the weights are NaN (as in the reference, which divides the same way), and the
+    next update of a sane set is exact again (the slots of the other launch parity were put back)."""
+    sc_ = Scenario(orc, size=200, n=6000, beams=61)  # three look-back tiles
+    good = sc_.samples.copy()
+    sc_.samples[:, 3] = np.inf
+    m, sc, pf, data = sc_.gpu_objects(engine, 61, "lf")
+    sc.updateSensor(pf, data)
+    assert np.all(np.isnan(pf.getCurrentSet().samples[:, 3]))
+    want = good.copy()
+    total = sc_.oracle_apply(sc_.oracle_planar(61, "lf"), want)
+    for _ in range(2):  # both launch parities
+        pf.initWithSamples(good)
+        sc.updateSensor(pf, data)
+        got = pf.getCurrentSet().samples
+        assert rel_err(got[:, 3], want[:, 3] / total).max() <= W_TOL
+
+
 def _oracle_resample_from(orc, samples, w_slow, w_fast, leaf_count, seed, model, min_s, max_s, pop=None):
     opf = orc.ParticleFilter(min_s, max_s, 0.0, 0.0, 85.0, seed=seed)
     opf.set_samples(samples, leaf_count=leaf_count)
