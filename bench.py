@@ -291,13 +291,16 @@ def workload_name(args, world):
     if key == ("lf", 5000, 181, 400):
         return "2D likelihood-field, 5000 particles, 181-beam scan, 400x400 static map (configs[0]: the reference's CPU case)"
     if key == ("beam", 100000, 1081, 2000):
-        return "2D beam-model raycast, 100k particles, 1081 beams, 2000x2000 map"
+        return "2D beam-model raycast, 100k particles, 1081 beams, 2000x2000 map" + (
+            "" if world == 1 else " -- per GPU: ONE filter of %d particles sharded over %d GPUs" % (100000 * world, world))
     if key == ("lf", 125000, 1081, 2000):
         return ("2D likelihood-field, 125k particles per GPU (configs[3]: 1M particles sharded over 8 GPUs; this run: "
                 "%d GPU%s, %d particles)" % (world, "" if world == 1 else "s", 125000 * world))
     if args.model == "cloud3d":
         return "3D (octomap) likelihood-field, %s particles, 64x1024-point cloud" % (
-            "200k" if args.particles == 200000 else str(args.particles))
+            "200k" if args.particles == 200000 else str(args.particles)) + (
+            "" if world == 1 else " -- per GPU: ONE filter of %d particles sharded over %d GPUs" % (
+                args.particles * world, world))
     return "2D %s, %d particles/GPU, %d beams, %dx%d map" % (args.model, args.particles, args.beams, args.map_size,
                                                            args.map_size)
 
