@@ -434,12 +434,6 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   HIPCHK(e, e->d_kld_flags.reserve(4 + kMaxLevels));
   HIPCHK(e, e->h_kld.reserve(4 + kMaxLevels));
   ProfScope ps(e, BPF_K_DRAW);
-  HIPCHK(e, hipMemsetAsync(e->d_kld_hkey.p, 0xFF, (size_t)table * sizeof(unsigned long long), e->stream));
-  HIPCHK(e, hipMemsetAsync(e->d_kld_htmin.p, 0x7F, (size_t)table * sizeof(int), e->stream));
-  HIPCHK(e, hipMemsetAsync(e->d_kld_first.p, 0x7F, (size_t)n * sizeof(int), e->stream));
-  HIPCHK(e, hipMemsetAsync(e->d_kld_child.p, 0x7F, (size_t)2 * n * sizeof(int), e->stream));
-  HIPCHK(e, hipMemsetAsync(e->d_kld_flags.p, 0, (4 + kMaxLevels) * sizeof(int), e->stream));
-  HIPCHK(e, hipMemsetAsync(e->d_kld_flags.p + 2, 0x7F, sizeof(int), e->stream));
   KldArgs K{};
   K.keys = e->d_keys.p;
   K.n = n;
@@ -454,6 +448,8 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   K.flags = e->d_kld_flags.p;
   K.limit = e->d_kld_limit.p;
   const dim3 grid(blocks_for(n, 256)), block(256);
+  hipLaunchKernelGGL(k_kld_clear, dim3(std::min(1024, blocks_for((int)std::max<unsigned>(table, 2u * (unsigned)n), 256))),
+                     block, 0, e->stream, K, table, 4 + kMaxLevels);
   hipLaunchKernelGGL(k_kld_hash, grid, block, 0, e->stream, K);
   if (e->kld_persistent)
   {

@@ -92,6 +92,25 @@ __device__ __forceinline__ void block_atomic_min(int* base, unsigned a, int i, b
       atomicMin(&base[s_tag[s]], s_val[s]);
 }
 
+// the tree's tables in their start state, one launch instead of six memsets (~4.4 us each): hash keys all-ones, the
+// int tables 0x7F7F7F7F ("later than any draw"), the flag words zero except the stop index
+__global__ void k_kld_clear(const KldArgs A, unsigned table, int n_flags)
+{
+  const unsigned stride = gridDim.x * blockDim.x;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (unsigned i = t; i < table; i += stride)
+  {
+    A.h_key[i] = kKldEmpty;
+    A.h_tmin[i] = 0x7F7F7F7F;
+  }
+  for (unsigned i = t; i < (unsigned)A.n; i += stride)
+    A.first[i] = 0x7F7F7F7F;
+  for (unsigned i = t; i < 2u * (unsigned)A.n; i += stride)
+    A.child[i] = 0x7F7F7F7F;
+  for (unsigned i = t; i < (unsigned)n_flags; i += stride)
+    A.flags[i] = (i == 2u) ? 0x7F7F7F7F : 0;
+}
+
 // pass 1: fold repeated keys; tmin[slot] = first draw with that key.  The block folds its own repeats in LDS first: a
 // converged set of 10^5 samples has ~50 distinct keys, and 2 000 same-address atomics per table slot serialise in L2
 // (~80 ns each: the launch took 257 us); with one insertion per distinct key and block it takes what a spread set does.
