@@ -576,6 +576,12 @@ def main():
         for k in ("issue_frac", "hbm_measured_gbs"):
             if k in ev:
                 line["roofline"][k] = ev[k]
+        if args.model in ("lf", "gompertz") and k_ms > 0:
+            # what the kernel really gathers per evaluation is a 2-byte level id (SURVEY 8(d) counts the reference's
+            # 4-byte float): the same launch priced at the bytes it touches, for whoever wants that figure
+            touched = 2.0 * wl["n"] * wl["beams"] + 40.0 * wl["n"] + 16.0 * wl["beams"]
+            line["roofline"]["gathered_bytes_per_eval"] = 2
+            line["roofline"]["achieved_at_gathered_bytes_gbs"] = touched / (k_ms * 1e-3) / 1e9
         if mean_cells is not None and args.model == "beam":
             line["roofline"]["mean_cells_per_ray"] = mean_cells
         os.write(json_fd, (json.dumps(line) + "\n").encode())
