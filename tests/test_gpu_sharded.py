@@ -23,6 +23,8 @@ def _free_port():
     return p
 
 
+# update + resample cycles of the two-rank comparison (BPF_SHARD_CYCLES=150 turns it into a soak of the exchanges)
+CYCLES = int(os.environ.get("BPF_SHARD_CYCLES", "2"))
 ODOM = (2, 0.05, 0.04, 0.03, 0.02, 0.0)                         # diff-corrected
 ODATA = ((1.0, 2.0, 0.3), (0.03, -0.01, 0.02), (0.03, 0.01, 0.02))  # pose, delta, absolute motion
 
@@ -66,7 +68,7 @@ def _worker(rank, world, port, out_dir, cloud, device_min, resampler, exchange):
     od = bpf.Odom(e)
     od.setModel(*ODOM)
     recs = []
-    for cycle in range(2):
+    for cycle in range(CYCLES):
         sf.update_action(od, bpf.OdomData(*ODATA))
         sf.update_sensor(data)
         w_after = pf.getCurrentSet().samples.copy()
@@ -102,7 +104,7 @@ def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min, r
     pf.setResampleModel(resampler)
     od = bpf.Odom(e)
     od.setModel(*ODOM)
-    for cycle in range(2):
+    for cycle in range(CYCLES):
         od.updateAction(pf, bpf.OdomData(*ODATA))
         scn.updateSensor(pf, data)
         w_ref = pf.getCurrentSet().samples[:, 3].copy()
