@@ -902,6 +902,11 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
 
   int M, status;
   fused_stop_rule(S, L, A.window, A.systematic, A.max_samples, act, pk, &M, &status);
+  // The host needs (M, leaf count, bin count, status) and nothing of what follows: it gets them now and spends its
+  // turn-around (its bookkeeping, the next launches, which the stream orders behind this one) while the block writes
+  // the weights and counts the converged samples.
+  if (tid == 0 && !A.debug)
+    fused_publish(A.result_host, A.generation, M, S.leaf, S.bins, status, S.levels);
 
   // ---- weights 1 / M (:409,458-462) and updateConverged (:170-220) in k_resample_tail_small's summation shape,
   // from the poses staged in LDS
@@ -959,12 +964,13 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
     volatile int* out = A.result_host;
     if (A.debug)
     {
+      // with the phase clocks: everything at the end, so that the clocks are there when the result is
       out[6] = (int)(clock64() - shader_clk0);
       for (int k = 0; k < 12; ++k)
         out[8 + k] = S.stamp[k];
       __threadfence_system();
+      fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);
     }
-    fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);
   }
 }
 
@@ -1069,6 +1075,8 @@ __global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A
 
   int M, status;
   fused_stop_rule(S, L, A.count, A.systematic, A.max_samples, act, pk, &M, &status);
+  if (tid == 0 && !A.debug)
+    fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);  // (the host's turn-around runs beside the tail)
 
   if (status == 0)
   {
@@ -1135,8 +1143,8 @@ __global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A
       for (int k = 0; k < 8; ++k)
         out[8 + k] = S.stamp[k];
       __threadfence_system();
+      fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);
     }
-    fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);
   }
 }
 
