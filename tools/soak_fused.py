@@ -1,4 +1,5 @@
-"""Soak of the fence-free hand-offs (k_normalize_cdf's look-back slots, k_resample_block's write-through draws):
+"""Soak of the fence-free hand-offs (k_normalize_cdf's look-back slots, k_resample_block's write-through draws; a
+different scan every step, so that a stale staging block would show as well):
 many update + resample cycles on varying sets, fused launches against the separate launches with the host replay,
 bit for bit (weights after the update, set / counts / RNG state after the resample).  A stale read between blocks
 would show as a differing CDF or draw.  usage (GPU box): python3 tools/soak_fused.py [cycles]"""
@@ -14,7 +15,7 @@ cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 size, beams = 2000, 181
 cells, origin = synth.make_map(size)
 pose = synth.true_pose(size)
-ranges, angles = synth.cast_scan(cells, origin, 0.05, pose, beams, seed=5)
+scans = [bpf.PlanarData(*synth.cast_scan(cells, origin, 0.05, pose, beams, seed=5 + k), 30.0) for k in range(7)]
 engines = []
 for fused in (1, 0):
     e = bpf.Engine(0)
@@ -24,7 +25,6 @@ for fused in (1, 0):
     sc = bpf.PlanarScanner(e); sc.init(beams, m); sc.setModelLikelihoodField(0.95, 0.05, 0.2, 2.0)
     sc.setMapFactors(0.95, 0.95, 0.3); sc.setPlanarScannerPose((0.1, 0.0, 0.0))
     engines.append((e, sc))
-data = bpf.PlanarData(ranges, angles, 30.0)
 rng = np.random.default_rng(7)
 bad = 0
 used = 0
@@ -43,7 +43,7 @@ for c in range(cycles):
         pf.initWithSamples(s)
         rec = []
         for k in range(3):
-            sc.updateSensor(pf, data)
+            sc.updateSensor(pf, scans[(c + k) % 7])  # another scan every step: a stale staging block would show
             w = pf.getCurrentSet().samples[:, 3].copy()
             pf.updateResample()
             st = pf.getState()
