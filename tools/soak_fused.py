@@ -30,15 +30,22 @@ bad = 0
 used = 0
 t0 = time.time()
 for c in range(cycles):
-    n = int(rng.choice([3000, 6000, 20000, 50000, 100000]))
-    sig = float(rng.choice([0.05, 0.3, 1.0]))
+    n = int(rng.choice([1, 7, 130, 1000, 3000, 6000, 20000, 50000, 100000]))
+    sig = float(rng.choice([0.05, 0.3, 1.0, 4.0]))
     s = synth.converged_cloud(n, pose, seed=1000 + c, sigma=(sig, sig, sig / 3))
+    if c % 5 == 4 and n >= 1000:  # every fifth set: half of it anywhere on the map (off-map and in-wall poses included)
+        s[: n // 2] = synth.spread_cloud(n // 2, size, 0.05, seed=2000 + c)
+        s[:, 3] = 1.0 / n
     s[:, 3] *= rng.uniform(0.5, 1.5, n)
     resampler = int(rng.integers(0, 2))
+    min_s = int(rng.choice([1, 10, 100, 500]))
+    max_s = int(rng.choice([n, max(n, 2 * min_s), max(min_s + 1, n // 3 + 1)]))
+    pop = [(0.01, 0.99), (0.05, 0.99), (0.0025, 0.9975)][int(rng.integers(0, 3))]
     out = []
     for e, sc in engines:
-        pf = bpf.ParticleFilter(e, 100, n, 0.0, 0.0, 85.0)
+        pf = bpf.ParticleFilter(e, min(min_s, max_s), max(max_s, n), 0.0, 0.0, 85.0)
         pf.setResampleModel(resampler)
+        pf.setPopulationSizeParameters(*pop)
         pf.srand48(c)
         pf.initWithSamples(s)
         rec = []
@@ -56,8 +63,8 @@ for c in range(cycles):
         used += a[7] == 2
         if not same:
             bad += 1
-            print("MISMATCH cycle %d step %d n %d sigma %.2f resampler %d: M %d/%d leaf %d/%d" % (
-                c, k, n, sig, resampler, a[2], b[2], a[3], b[3]))
+            print("MISMATCH cycle %d step %d n %d sigma %.2f resampler %d min %d max %d pop %r: M %d/%d leaf %d/%d" % (
+                c, k, n, sig, resampler, min_s, max_s, pop, a[2], b[2], a[3], b[3]))
 print("%d cycles x 3 steps, %d through the single-launch resample, %d mismatches, %.0f s" % (
     cycles, used, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
