@@ -151,7 +151,17 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
     long long* window = X.next_window(sys_count, &stride);
     if (!window)
       return e->last_status;
-    rc = bpf_shard_systematic_window_dev(e, rng, sys_count, e->mb_totals, 1, rank, W, window, stride, flags_dev);
+    const bool tracking = e->fused_resample && sys_count <= kFusedWindow;
+    const bool merged = tracking && !X.collective();  // mailbox: the draws and their consumer in ONE launch
+    WindowArgs draw{};
+    if (merged)
+    {
+      size_t lds_unused = 0;
+      rc = systematic_window_args(e, rng, sys_count, e->mb_totals, 1, rank, W, window, stride, flags_dev, &draw,
+                                  &lds_unused);
+    }
+    else
+      rc = bpf_shard_systematic_window_dev(e, rng, sys_count, e->mb_totals, 1, rank, W, window, stride, flags_dev);
     if (rc != BPF_OK)
       return rc;
     rc = X.assemble(window, stride);
@@ -159,10 +169,13 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
       return rc;
     *windows_out = 1;
     int fused_status = BPF_FUSED_TOO_MANY_BINS;
-    if (e->fused_resample && sys_count <= kFusedWindow)
+    if (tracking)
     {
       // tree of the new set (every sample, no stop rule), adoption and updateConverged in one launch
-      rc = shard_stop_block(e, window, stride, sys_count, true, &fused_status, &M, &leaf, &bins);
+      rc = shard_stop_block(e, window, stride, sys_count, true, &fused_status, &M, &leaf, &bins,
+                            merged ? &draw : nullptr);
+      if (rc == BPF_OK && merged)
+        rc = systematic_targets_in_use(e);
       if (rc != BPF_OK)
         return rc;
     }
@@ -231,18 +244,27 @@ int bpf_shard_mailbox_update_resample(bpf_engine* e, void* flags_dev, int* globa
       long long* window = X.next_window(cnt, &stride);
       if (!window)
         return e->last_status;
-      rc = bpf_shard_draw_window_dev(e, rng, m0, m1, e->mb_totals, 1, rank, W, window, stride, flags_dev);
+      const bool tracking = m0 == 0 && e->fused_resample && cnt <= kFusedWindow && *window_hint_io <= kFusedWindow;
+      WindowArgs draw{};
+      const bool merged = tracking && !X.collective();  // mailbox: the draws and their consumer in ONE launch
+      if (merged)
+      {
+        size_t lds_unused = 0;
+        rc = draw_window_args(e, rng, m0, m1, e->mb_totals, 1, rank, W, window, stride, flags_dev, &draw, &lds_unused);
+      }
+      else
+        rc = bpf_shard_draw_window_dev(e, rng, m0, m1, e->mb_totals, 1, rank, W, window, stride, flags_dev);
       if (rc != BPF_OK)
         return rc;
       rc = X.assemble(window, stride);
       if (rc != BPF_OK)
         return rc;
-      if (m0 == 0 && e->fused_resample && cnt <= kFusedWindow && *window_hint_io <= kFusedWindow)
+      if (tracking)
       {
         // the tracking regime: the stream is expected to stop inside this first window, and the stop rule, the
         // adoption of this rank's share and updateConverged run in one single-block launch on every rank
         int fused_status = BPF_FUSED_TOO_MANY_BINS;
-        rc = shard_stop_block(e, window, stride, cnt, false, &fused_status, &M, &leaf, &bins);
+        rc = shard_stop_block(e, window, stride, cnt, false, &fused_status, &M, &leaf, &bins, merged ? &draw : nullptr);
         if (rc != BPF_OK)
           return rc;
         if (fused_status == BPF_FUSED_OK)

@@ -287,14 +287,19 @@ MailboxDev shard_window_wait(bpf_engine* e, const void* window_dev, int consumer
 }
 }  // namespace
 
-int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev,
-                              int sums_are_totals, int rank, int world, void* window_dev, int stride, void* flags_dev)
+namespace
+{
+// the arguments of a multinomial draw window (k_draw_window, k_shard_resample_block); *lds_out = the dynamic LDS the
+// CDF subsample takes in k_draw_window (0: none)
+int draw_window_args(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev, int sums_are_totals,
+                     int rank, int world, void* window_dev, int stride, void* flags_dev, WindowArgs* out, size_t* lds_out)
 {
   if (!e || !e->have_pf || !sums_dev || !window_dev || !flags_dev || m1 <= m0 || stride < m1 - m0 || rank < 0 ||
       rank >= world)
     return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "bad draw window arguments") : BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
-  WindowArgs A{};
+  WindowArgs& A = *out;
+  A = WindowArgs{};
   A.src = e->sets[e->cur].dev();
   A.n_src = e->sample_count;
   A.cdf = e->d_cdf.p;
@@ -339,6 +344,20 @@ int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m
     A.coarse_shift = fused_coarse_shift(A.n_src);
     lds = ((size_t)((A.n_src - 1) >> A.coarse_shift) + 2) * sizeof(double);
   }
+  *lds_out = lds;
+  return BPF_OK;
+}
+}  // namespace
+
+int bpf_shard_draw_window_dev(bpf_engine* e, uint64_t rng_state48, int m0, int m1, const void* sums_dev,
+                              int sums_are_totals, int rank, int world, void* window_dev, int stride, void* flags_dev)
+{
+  WindowArgs A{};
+  size_t lds = 0;
+  int rc = draw_window_args(e, rng_state48, m0, m1, sums_dev, sums_are_totals, rank, world, window_dev, stride, flags_dev,
+                            &A, &lds);
+  if (rc != BPF_OK)
+    return rc;
   ProfScope ps(e, BPF_K_DRAW);
   hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(m1 - m0, 256)), dim3(256), lds, e->stream, A);
   HIPCHK(e, hipGetLastError());
@@ -404,7 +423,7 @@ namespace
 // another BPF_FUSED_* when the window is outside what the kernel takes -- nothing was changed and the window stays
 // readable for the stage-by-stage path.
 int shard_stop_block(bpf_engine* e, const long long* window, int stride, int count, bool systematic, int* status,
-                     int* M_out, int* leaf_out, int* bins_out)
+                     int* M_out, int* leaf_out, int* bins_out, const WindowArgs* draw = nullptr)
 {
   *status = BPF_FUSED_TOO_MANY_BINS;
   if (count <= 0 || count > kFusedWindow || stride < count)
@@ -443,6 +462,23 @@ int shard_stop_block(bpf_engine* e, const long long* window, int stride, int cou
   e->fused_generation = (e->fused_generation % 0x3fffffff) + 1;
   A.generation = e->fused_generation;
   A.debug = getenv("BPF_DEBUG") != nullptr;
+  if (draw != nullptr)
+  {
+    // mailbox mode: the draws of the window and their consumer in one launch (k_shard_resample_block)
+    if (!e->shard_resample_attr_set)
+    {
+      HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_shard_resample_block),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+      e->shard_resample_attr_set = true;
+    }
+    ShardResampleArgs R{};
+    R.W = *draw;
+    R.S = A;
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_shard_resample_block, dim3(blocks_for(count, kFusedDrawsPerBlock)), dim3(1024), kFusedLds,
+                       e->stream, R);
+  }
+  else
   {
     ProfScope ps(e, BPF_K_FINALIZE);
     hipLaunchKernelGGL(k_shard_stop_block, dim3(1), dim3(1024), kFusedLds, e->stream, A);
@@ -677,9 +713,12 @@ int bpf_pf_resample_limit(bpf_engine* e, int leaf_count, int* count_out)
   return BPF_OK;
 }
 
-int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int count, const void* sums_dev,
-                                    int sums_are_totals, int rank, int world, void* window_dev, int stride,
-                                    void* flags_dev)
+namespace
+{
+// the arguments of a systematic draw window; the caller launches (and records targets_read behind the launch)
+int systematic_window_args(bpf_engine* e, uint64_t rng_state48, int count, const void* sums_dev, int sums_are_totals,
+                           int rank, int world, void* window_dev, int stride, void* flags_dev, WindowArgs* out,
+                           size_t* lds_out)
 {
   if (!e || !e->have_pf || !sums_dev || !window_dev || !flags_dev || count <= 0 || stride < count || rank < 0 ||
       rank >= world)
@@ -703,7 +742,8 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
     if (t > 1.0)
       t -= 1.0;
   }
-  WindowArgs A{};
+  WindowArgs& A = *out;
+  A = WindowArgs{};
   A.src = e->sets[e->cur].dev();
   A.n_src = e->sample_count;
   A.cdf = e->d_cdf.p;
@@ -730,22 +770,43 @@ int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int cou
   int rcm = shard_window_exchange(e, window_dev, count, world, &A);
   if (rcm != BPF_OK)
     return rcm;
+  size_t lds = 0;
+  if (e->cdf_coarse_n == A.n_src && A.n_src > 0 && count <= 2 * kFusedWindow)
   {
-    size_t lds = 0;
-    if (e->cdf_coarse_n == A.n_src && A.n_src > 0 && count <= 2 * kFusedWindow)
-    {
-      A.coarse = e->d_cdf_coarse.p;
-      A.coarse_shift = fused_coarse_shift(A.n_src);
-      lds = ((size_t)((A.n_src - 1) >> A.coarse_shift) + 2) * sizeof(double);
-    }
-    ProfScope ps(e, BPF_K_DRAW);
-    hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(count, 256)), dim3(256), lds, e->stream, A);
+    A.coarse = e->d_cdf_coarse.p;
+    A.coarse_shift = fused_coarse_shift(A.n_src);
+    lds = ((size_t)((A.n_src - 1) >> A.coarse_shift) + 2) * sizeof(double);
   }
-  HIPCHK(e, hipGetLastError());
+  *lds_out = lds;
+  return BPF_OK;
+}
+
+// a window kernel that reads the pinned systematic targets has been launched: the next targets wait for it
+int systematic_targets_in_use(bpf_engine* e)
+{
   if (!e->targets_read)
     HIPCHK(e, hipEventCreateWithFlags(&e->targets_read, hipEventDisableTiming));
   HIPCHK(e, hipEventRecord(e->targets_read, e->stream));
   return BPF_OK;
+}
+}  // namespace
+
+int bpf_shard_systematic_window_dev(bpf_engine* e, uint64_t rng_state48, int count, const void* sums_dev,
+                                    int sums_are_totals, int rank, int world, void* window_dev, int stride,
+                                    void* flags_dev)
+{
+  WindowArgs A{};
+  size_t lds = 0;
+  int rc = systematic_window_args(e, rng_state48, count, sums_dev, sums_are_totals, rank, world, window_dev, stride,
+                                  flags_dev, &A, &lds);
+  if (rc != BPF_OK)
+    return rc;
+  {
+    ProfScope ps(e, BPF_K_DRAW);
+    hipLaunchKernelGGL(k_draw_window, dim3(blocks_for(count, 256)), dim3(256), lds, e->stream, A);
+  }
+  HIPCHK(e, hipGetLastError());
+  return systematic_targets_in_use(e);
 }
 
 int bpf_kld_insert(bpf_engine* e, const void* keys, int keys_are_int64, int stride, int n_keys)

@@ -240,6 +240,7 @@ struct bpf_engine
   bool fused_resample = true; // BPF_OPT_FUSED_RESAMPLE
   bool fused_lds_attr_set = false;
   bool shard_stop_attr_set = false;
+  bool shard_resample_attr_set = false;
   bool kld_persistent = false;         // BPF_OPT_KLD_PERSISTENT: the device tree in one launch when its grid is resident
   int kld_generation = 0;
   int kld_persist_blocks_per_cu = -1;  // occupancy of k_kld_tree_persistent (-1: not asked yet)

@@ -1004,11 +1004,9 @@ struct ShardStopArgs
 
 constexpr int BPF_FUSED_EXCHANGE = 5;  // the window did not arrive (mailbox time-out): nothing was written
 
-__global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A)
+// the body of k_shard_stop_block (every thread of the 1 024-thread block calls it)
+__device__ __forceinline__ void shard_stop_body(const ShardStopArgs& A, FusedStatics& S, const FusedLdsMap& L)
 {
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ FusedStatics S;
-  const FusedLdsMap L = fused_lds_map(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int Q = kFusedPerThread;
   volatile int* out = A.result_host;
@@ -1146,6 +1144,89 @@ __global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A
       fused_publish(out, A.generation, M, S.leaf, S.bins, status, S.levels);
     }
   }
+}
+
+
+__global__ __launch_bounds__(1024) void k_shard_stop_block(const ShardStopArgs A)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ FusedStatics S;
+  const FusedLdsMap L = fused_lds_map(smem);
+  shard_stop_body(A, S, L);
+}
+
+// Mailbox mode, tracking regime: the draw window AND its consumer in one launch.  grid = ceil(draws / 128) blocks; every
+// block resolves its draws (k_draw_window's column function), stores the columns this shard owns into all peers'
+// windows and takes a ticket; the block that takes the last one posts this shard's "done" word to every peer and goes
+// on as k_shard_stop_block does (wait for the W "done" words, stop rule, adoption, updateConverged).  One launch and
+// one launch boundary less per resample than k_draw_window followed by k_shard_stop_block.
+struct ShardResampleArgs
+{
+  WindowArgs W;
+  ShardStopArgs S;
+};
+
+__global__ __launch_bounds__(1024) void k_shard_resample_block(const ShardResampleArgs A)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ FusedStatics S;
+  __shared__ double s_sums[kMailboxMaxWorld];
+  __shared__ double s_slice[2];
+  const FusedLdsMap L = fused_lds_map(smem);
+  const WindowArgs& D = A.W;
+  const int tid = threadIdx.x;
+  double* s_coarse = nullptr;
+  if (D.coarse != nullptr)
+  {
+    s_coarse = reinterpret_cast<double*>(L.hash);  // (as in k_resample_block: [W + 1] doubles)
+    const int n_coarse = ((D.n_src - 1) >> D.coarse_shift) + 1;
+    for (int k = tid; k <= n_coarse; k += 1024)
+      s_coarse[k] = D.coarse[k];
+  }
+  if (tid < D.world)
+    s_sums[tid] = D.sums[tid];
+  __syncthreads();
+  if (tid == 0)
+    shard_slice(s_sums, D.sums_are_totals, D.rank, D.world, &s_slice[0], &s_slice[1]);
+  __syncthreads();
+  // 128 draws per block (its first two waves), as in k_resample_block: a CU's texture path takes about one cache line
+  // per clock, so the window's random gathers want many CUs
+  const int o = blockIdx.x * kFusedDrawsPerBlock + tid;
+  const bool live = tid < kFusedDrawsPerBlock && D.m0 + o < D.m1;
+  long long out[6] = { 0, 0, 0, 0, 0, 0 };
+  const bool owned = live && draw_window_column(D, o, out, s_slice[0], s_slice[1], s_coarse);
+  if (owned)
+    for (int r = 0; r < D.mb.world; ++r)
+    {
+      long long* win = mb_window(D.mb.peer[r], D.mb_parity, D.mb.max_window);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        win[(size_t)k * (size_t)D.mb.max_window + o] = out[k];
+    }
+  // every storing wave drains its peer stores, one system-scope release per block, the ticket; the last block posts
+  // "done" (mb_window_done_when_last, with the block kept instead of retired)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+  {
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(D.mb_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    S.last = prev == gridDim.x - 1;
+    if (S.last)
+    {
+      __hip_atomic_store(D.mb_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int r = 0; r < D.mb.world; ++r)
+        __hip_atomic_store(mb_win_done(D.mb.peer[r], D.mb_parity, D.mb.rank), D.mb_gen, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  if (!S.last)
+    return;
+  shard_stop_body(A.S, S, L);
 }
 
 }  // namespace bpf

@@ -87,8 +87,8 @@ def _worker(rank, world, port, out_dir, cloud, device_min, resampler, exchange):
 @pytest.mark.parametrize("cloud,device_min,resampler", [("converged", 8192, 0), ("spread", 512, 0),
                                                         ("converged", 8192, 1)])
 def test_two_ranks_on_one_gpu_equal_single_engine(tmp_path, cloud, device_min, resampler, exchange):
-    """converged: early KLD stop inside the first window (mailbox: k_shard_stop_block on every rank; collective and
-    mailbox-staged: the host's ordered replay).  spread with a low device threshold: no stop in the first window, so
+    """converged: early KLD stop inside the first window (mailbox: k_shard_resample_block on every rank, the draws and
+    their consumer in one launch; collective and mailbox-staged: the host's ordered replay).  spread with a low device threshold: no stop in the first window, so
     one window with the whole stream follows and the stop rule runs on the device."""
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
