@@ -427,7 +427,7 @@ __device__ __forceinline__ int fused_tree(int my, bool have, const unsigned long
 #define BPF_FUSED_STAMP(k)                                                   \
   do                                                                         \
   {                                                                          \
-    if (threadIdx.x == 0)                                                    \
+    if (threadIdx.x == 0 && S.debug)                                         \
       S.stamp[k] = (int)(unsigned)wall_clock64();                            \
   } while (0)
 
@@ -435,6 +435,7 @@ __device__ __forceinline__ int fused_tree(int my, bool have, const unsigned long
 struct FusedStatics
 {
   int stop, bad, leaf, bins, count, levels, last;
+  int debug;  // phase clocks wanted (BPF_DEBUG); set by thread 0 first thing, read by thread 0 only
   int stamp[16];
   int wx[16];
   int limit[kFusedMaxBins + 1];
@@ -713,6 +714,8 @@ __global__ __launch_bounds__(1024) void k_resample_block(const ResampleBlockArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int Q = kFusedPerThread;
   const bool stamps = blockIdx.x == 0;
+  if (tid == 0)
+    S.debug = A.debug;
   if (stamps)
     BPF_FUSED_STAMP(0);
 
@@ -1010,6 +1013,8 @@ __device__ __forceinline__ void shard_stop_body(const ShardStopArgs& A, FusedSta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int Q = kFusedPerThread;
   volatile int* out = A.result_host;
+  if (tid == 0)
+    S.debug = A.debug;
   BPF_FUSED_STAMP(0);
   if (A.mb.world > 0 && !mb_block_wait(A.mb, mb_win_done(A.mb.peer[A.mb.rank], A.wait_parity, 0), A.wait_gen, 1))
   {
