@@ -185,6 +185,15 @@ __device__ unsigned long long g_cloud_span[8192][2];  // diagnostic builds: per-
 // exact) and its x, y are a 2-D rotation (the r2 * pz and r5 * pz terms add an exact zero).  The z voxel, its clamp and
 // its range test are then formed once per chunk at staging and kept in LDS in place of pz.
 // DENSE: one gather from Map3dDev::dense instead of the two-level pair.
+// min(max(c, 1), hi) in ONE instruction (hi >= 1): the compiler keeps v_max_u32 + v_min_u32 because it cannot see
+// that the bounds are ordered -- two of the kernel's ~29 vector instructions per evaluation
+__device__ __forceinline__ unsigned clamp_1_to(unsigned c, unsigned hi)
+{
+  unsigned r;
+  asm("v_med3_u32 %0, %1, 1, %2" : "=v"(r) : "v"(c), "s"(hi));
+  return r;
+}
+
 template <bool EXACT_RINV, bool PLANAR, bool DENSE>
 __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
 {
@@ -194,7 +203,9 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
 #endif
   __shared__ float s_pts[3][kCloudChunk];
   // [0, 256): the term per distance ratio; [256]: the off-map term; [257]: zero (padding lanes of the last group).
-  // An evaluation's byte offset is max(ratio << 3, bad) with bad = 0 (on the map), 2048 or 2056.
+  // An evaluation's byte offset is max(ratio << 3, bad) with bad = 0 (on the map), 2048 or 2056.  (The off-map and zero
+  // entries 256 times each, so that the offset is one v_lshl_or_b32: the 4 KB more LDS cost a block per CU and the
+  // instruction saved bought nothing: 8.61 against 8.59 ms.)
   __shared__ double s_table[258];
   const int chunk = blockIdx.x;
   const int p0 = chunk * kCloudChunk;
@@ -290,8 +301,8 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
                                      : voxel1(wy, M.resolution, M.inv_resolution, M.min_c[1]);
       const unsigned cz = EXACT_RINV ? voxel1_exact(wz, M.inv_resolution, hm2)
                                      : voxel1(wz, M.resolution, M.inv_resolution, M.min_c[2]);
-      const unsigned xi = min(max(ci, 1u), span_x + 1u), xj = min(max(cj, 1u), span_y + 1u);
-      ck = min(max(cz, 1u), span_z + 1u);
+      const unsigned xi = clamp_1_to(ci, span_x + 1u), xj = clamp_1_to(cj, span_y + 1u);
+      ck = clamp_1_to(cz, span_z + 1u);
       const bool ok = xi == ci && xj == cj && ck == cz;
       if (DENSE)
         col = __umul24(ck, M.dense_plane) + ((xi << 3) + (__umul24(xj & ~7u, M.dense_k) + xj));
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
                                      : voxel1(wx, M.resolution, M.inv_resolution, M.min_c[0]);
       const unsigned cj = EXACT_RINV ? voxel1_exact(wy, M.inv_resolution, hm1)
                                      : voxel1(wy, M.resolution, M.inv_resolution, M.min_c[1]);
-      const unsigned xi = min(max(ci, 1u), span_x + 1u), xj = min(max(cj, 1u), span_y + 1u);
+      const unsigned xi = clamp_1_to(ci, span_x + 1u), xj = clamp_1_to(cj, span_y + 1u);
       const bool ok = xi == ci && xj == cj;
       if (DENSE)
         col = (xi << 3) + (__umul24(xj & ~7u, M.dense_k) + xj);
@@ -373,22 +384,29 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
     };
     // Software pipeline over the groups: while the second-level gathers of group g are in flight, the cells and
     // first-level gathers of group g + 1 are formed and issued.
-    unsigned start_c[U], ck_c[U], bad_c[U];
-    stage1(0, start_c, ck_c, bad_c);
-    for (int g = 0; g < n_groups; ++g)
+    // Two register sets in turn (a single set had to be copied aside before the next group overwrote it: eight moves
+    // per group of four evaluations).
+    unsigned start_a[U], ck_a[U], bad_a[U], start_b[U], ck_b[U], bad_b[U];
+    auto consume = [&](const unsigned (&st)[U], const unsigned (&ck)[U], const unsigned (&bd)[U]) {
+      unsigned lvl[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        lvl[u] = DENSE ? st[u] : (unsigned)ratio_b[st[u] + ck[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        acc += *reinterpret_cast<const double*>(table_b + max(lvl[u] << 3, bd[u]));
+    };
+    stage1(0, start_a, ck_a, bad_a);
+    for (int g = 0; g < n_groups; g += 2)
     {
-      unsigned lvl[U], bad_now[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        lvl[u] = DENSE ? start_c[u] : (unsigned)ratio_b[start_c[u] + ck_c[u]];
-        bad_now[u] = bad_c[u];
-      }
       if (g + 1 < n_groups)
-        stage1(g + 1, start_c, ck_c, bad_c);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        acc += *reinterpret_cast<const double*>(table_b + max(lvl[u] << 3, bad_now[u]));
+        stage1(g + 1, start_b, ck_b, bad_b);
+      consume(start_a, ck_a, bad_a);
+      if (g + 1 >= n_groups)
+        break;
+      if (g + 2 < n_groups)
+        stage1(g + 2, start_a, ck_a, bad_a);
+      consume(start_b, ck_b, bad_b);
     }
     const double tot = wave_sum(acc);
     if (lane == 0)
