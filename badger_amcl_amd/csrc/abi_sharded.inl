@@ -22,7 +22,6 @@ int shard_local_total(bpf_engine* e)
   if (e->fused_partials > 0)
   {
     // the scoring kernel left per-block partials: one small launch folds them into the local total
-    ProfScope ps(e, BPF_K_REDUCE);
     if (e->mb.active)
     {
       // mailbox: the fold and the post to the peers ride on the normalise launch that has to follow anyway
@@ -33,6 +32,7 @@ int shard_local_total(bpf_engine* e)
       return BPF_OK;
     }
     const unsigned long long gen = 0;
+    ProfScope ps(e, BPF_K_REDUCE);
     hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_block_partials.p,
                        e->fused_partials, e->d_scalars.p, 0, mailbox_dev(e), (int)(gen & 1), gen);
     HIPCHK(e, hipGetLastError());
