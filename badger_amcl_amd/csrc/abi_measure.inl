@@ -26,7 +26,8 @@ int bpf_profile_enable(bpf_engine* e, int on)
     }
   }
   e->profiling = on != 0;
-  e->profile_all = on >= 2;
+  e->profile_all = on == 2;
+  e->timed_stride = on == 3 ? 1u : kTimedLaunchStride;
   return BPF_OK;
 }
 

@@ -8,15 +8,20 @@ int bpf_planar_init(bpf_engine* e, int max_beams)
   return BPF_OK;
 }
 
+int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist);  // abi_lut_reference.inl
+
 static int need_lut_for(bpf_engine* e, double max_dist)
 {
   // setModelLikelihoodField* call map_->updateDistancesLUT(max_dist) (planar_scanner.cpp:74,91,112).
-  // A host-provided LUT built for the same max_dist is kept; otherwise build on the device.
+  // A LUT already there for the same max_dist is kept; otherwise it is built as the reference builds it (host
+  // brushfire, the reference's values) unless the caller opted for the exact EDT on the device.
   if (!e->have_map)
     return BPF_OK;  // model may be set before the map; the LUT is then required at scoring time
   if (e->have_lut && e->map.max_dist == max_dist)
     return BPF_OK;
   HIPCHK(e, hipSetDevice(e->device));
+  if (!e->lut_exact_edt)
+    return bpf_map2d_build_distances_lut_reference(e, max_dist);
   return build_lut_device(e, max_dist);
 }
 

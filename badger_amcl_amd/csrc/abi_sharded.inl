@@ -904,6 +904,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->cloud_dense = value != 0;
   else if (option == BPF_OPT_LUT_HOST)
     e->lut_host = value != 0;
+  else if (option == BPF_OPT_LUT_EXACT_EDT)
+    e->lut_exact_edt = value != 0;
   else if (option == BPF_OPT_KLD_PERSISTENT)
     e->kld_persistent = value != 0;
   else if (option == BPF_OPT_STATS_HOST)

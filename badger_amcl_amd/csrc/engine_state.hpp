@@ -238,6 +238,7 @@ struct bpf_engine
   DevBuf<unsigned long long> d_tile_slots;  // k_normalize_cdf's look-back slots, [2][256]
   unsigned tile_generation = 0;
   bool fused_resample = true; // BPF_OPT_FUSED_RESAMPLE
+  bool lut_exact_edt = false; // BPF_OPT_LUT_EXACT_EDT: implicit LUT builds take the device EDT instead of the reference's brushfire
   bool fused_lds_attr_set = false;
   bool shard_stop_attr_set = false;
   bool shard_resample_attr_set = false;
@@ -381,7 +382,8 @@ struct bpf_engine
 
   // ---- profiling
   bool profiling = false;
-  unsigned timed_launches = 0;  // scoring launches seen in profile mode 1 (every kTimedLaunchStride-th is timed)
+  unsigned timed_launches = 0;  // scoring launches seen in profile mode 1 / 3 (every timed_stride-th is timed)
+  unsigned timed_stride = 8;    // mode 1: kTimedLaunchStride, mode 3: 1
   bool profile_all = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
   std::vector<int> ev_class;

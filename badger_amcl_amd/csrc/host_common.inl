@@ -24,7 +24,9 @@ struct ProfScope
 // kernel's own start-to-end, without the marker packets and launch gap that hipEventRecord around a launch adds
 // (~3.5 us), and agrees with the rocprofv3 kernel trace.  A timed dispatch costs the step ~5 us (completion signal
 // with timestamps), so in mode 1 (scoring kernels only, used inside bench.py's timed region) every
-// kTimedLaunchStride-th launch is timed, starting with the first after bpf_profile_reset; mode 2 times all.  Falls back to a plain launch when profiling is off.
+// kTimedLaunchStride-th launch is timed, starting with the first after bpf_profile_reset; mode 3 times every scoring
+// launch (for kernels of a millisecond or more, where 5 us do not show); mode 2 times all classes.  Falls back to a
+// plain launch when profiling is off.
 constexpr unsigned kTimedLaunchStride = 8;
 #define LAUNCH_TIMED(e, klass, kernel, grid, block, lds, ...)                                                         \
   do                                                                                                                  \
@@ -32,7 +34,7 @@ constexpr unsigned kTimedLaunchStride = 8;
     bpf_engine* _e = (e);                                                                                             \
     if (_e->profiling && _e->ev_used < _e->ev_start.size() &&                                                         \
         ((klass) == BPF_K_SCORE || (klass) == BPF_K_SCORE_WINDOW || _e->profile_all) &&                               \
-        (_e->profile_all || (_e->timed_launches++ % kTimedLaunchStride) == 0))                                        \
+        (_e->profile_all || (_e->timed_launches++ % _e->timed_stride) == 0))                                              \
     {                                                                                                                 \
       const int _idx = (int)_e->ev_used++;                                                                            \
       _e->ev_class[_idx] = (klass);                                                                                   \

@@ -28,6 +28,7 @@ OPT_CLOUD_DENSE = 6
 OPT_STATS_HOST = 7
 OPT_LUT_HOST = 8
 OPT_KLD_PERSISTENT = 9
+OPT_LUT_EXACT_EDT = 10
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 
@@ -79,7 +80,7 @@ class Engine:
         self.check(self.lib.bpf_synchronize(self.h))
 
     def profile_enable(self, on=1):
-        """1 = time the scoring kernel only, 2 = every kernel class, 0 = off."""
+        """1 = time every 8th launch of the scoring kernel, 3 = every launch of it, 2 = every kernel class, 0 = off."""
         self.check(self.lib.bpf_profile_enable(self.h, int(on)))
 
     def profile_reset(self):
@@ -162,16 +163,20 @@ class OccupancyMap:
         self._dirty = False
 
     def updateDistancesLUT(self, max_distance_to_object):
-        """Device EDT (exact); differs from the reference's approximate brushfire in a few cells."""
+        """OccupancyMap::updateDistancesLUT (occupancy_map.cpp:138-252): the reference's priority-queue brushfire, its
+        values bit for bit (host builder, once per map as in the reference)."""
         self.upload()
-        self.e.check(self.e.lib.bpf_map2d_build_distances_lut(self.e.h, float(max_distance_to_object)))
+        self.e.check(self.e.lib.bpf_map2d_build_distances_lut_reference(self.e.h, float(max_distance_to_object)))
         self.max_distance_to_object = float(max_distance_to_object)
         self.lut = None
 
-    def updateDistancesLUTReference(self, max_distance_to_object):
-        """The reference's priority-queue brushfire (occupancy_map.cpp:138-252), bit-identical LUT."""
+    updateDistancesLUTReference = updateDistancesLUT
+
+    def updateDistancesLUTExact(self, max_distance_to_object):
+        """NOT a reference method: the exact capped EDT built on the device (milliseconds); <= the brushfire's values
+        and different from them in < 1 % of the cells -- the caller's explicit choice."""
         self.upload()
-        self.e.check(self.e.lib.bpf_map2d_build_distances_lut_reference(self.e.h, float(max_distance_to_object)))
+        self.e.check(self.e.lib.bpf_map2d_build_distances_lut(self.e.h, float(max_distance_to_object)))
         self.max_distance_to_object = float(max_distance_to_object)
         self.lut = None
 

@@ -315,6 +315,10 @@ class ShardedFilter:
         # exchange: "mailbox" = peer stores through IPC-mapped device memory (all ranks on one node), "collective" =
         # torch.distributed all-gather / all-reduce, "auto" = mailbox when every rank could set it up
         self.mailbox = False
+        # what the bring-up found: "pass" (every rank created, mapped, completed the connect round and verified the
+        # four self-test windows cell by cell), "fail: <stage>" (some rank did not; the collectives carry the
+        # exchanges), "not run" (collectives requested)
+        self.mailbox_verdict = "not run"
         if exchange not in ("auto", "mailbox", "collective"):
             raise ValueError("exchange: auto, mailbox or collective")
         if exchange != "collective" and hasattr(backend, "mailbox_create") and self.world <= 16:
@@ -343,15 +347,40 @@ class ShardedFilter:
         handle = b.mailbox_create(self.rank, self.world, self.max_global)
         mine = torch.tensor(list(handle if handle is not None else bytes(64)), dtype=torch.uint8, device=self.device)
         handles = self._all_gather(mine).cpu().numpy().tobytes()
+        stage = "create / IPC export"
         ok = self._all_agree(handle is not None)
         if ok:
+            stage = "IPC map + connect round"
             ok = self._all_agree(b.mailbox_connect(handles))
         if ok:
             # the words arrive; do the window cells?  (a peer's stores must be visible behind this GPU's caches)
+            stage = "window self-test"
             ok = self._all_agree(b.mailbox_selftest())
         if not ok:
             b.mailbox_destroy()
+        self.mailbox_verdict = "pass" if ok else "fail: " + stage
         return ok
+
+    def use_collectives(self):
+        """Drop the mailbox and carry the exchanges over torch.distributed from the next update on (bench.py times
+        the same filter once per exchange; every rank calls this between two steps)."""
+        if self.mailbox:
+            self.b.mailbox_destroy()
+        self.mailbox = False
+        self._windows.clear()
+        self._pose_views.clear()
+        self.totals = None
+        self._fused_totals = False
+
+    def try_mailbox(self):
+        """(Re-)establish the mailbox between two steps; True when every rank could."""
+        if not self.mailbox and hasattr(self.b, "mailbox_create") and self.world <= 16:
+            self._windows.clear()
+            self._pose_views.clear()
+            self.totals = None
+            self._fused_totals = False
+            self.mailbox = self._setup_mailbox()
+        return self.mailbox
 
     # ---- a mailbox wait ran out of time (a rank stalled: page-in, debugger, a long host pause)
     def _is_exchange_error(self, err):

@@ -90,16 +90,20 @@ public:
     max_dist_ = max_distance_to_object;
     dirty_ = true;
   }
-  // the reference's own priority-queue brushfire (bit-identical LUT, host, ~2 s per 2000^2 map)
-  void updateDistancesLUTReference(double max_distance_to_object)
+  // OccupancyMap::updateDistancesLUT (occupancy_map.cpp:138-252): the reference's own priority-queue brushfire, the
+  // reference's values bit for bit (host, once per map as in the reference, ~0.7 s per 2000^2 map)
+  void updateDistancesLUT(double max_distance_to_object)
   {
     upload();
     e_->check(bpf_map2d_build_distances_lut_reference(e_->get(), max_distance_to_object));
     max_dist_ = max_distance_to_object;
     lut_.clear();
   }
-  // OccupancyMap::updateDistancesLUT on the device (exact EDT; see badger_pf.h)
-  void updateDistancesLUT(double max_distance_to_object)
+  void updateDistancesLUTReference(double max_distance_to_object) { updateDistancesLUT(max_distance_to_object); }
+  // NOT a reference method: the exact capped Euclidean distance transform, built on the device in milliseconds.  Its
+  // values are <= the brushfire's and differ from them in < 1 % of the cells, so weights differ from the reference's
+  // for particles whose beams end there -- an explicit choice of the caller (badger_pf.h, BPF_OPT_LUT_EXACT_EDT)
+  void updateDistancesLUTExact(double max_distance_to_object)
   {
     upload();
     e_->check(bpf_map2d_build_distances_lut(e_->get(), max_distance_to_object));
@@ -107,6 +111,14 @@ public:
     lut_.clear();
   }
   double getMaxDistanceToObject() const { return max_dist_; }
+  // distances_lut_ as the engine holds it (index i + j * size_x, occupancy_map.cpp:107-110)
+  std::vector<float> getDistancesLUT()
+  {
+    upload();
+    std::vector<float> out((size_t)size_x_ * size_y_);
+    e_->check(bpf_map2d_get_distances_lut(e_->get(), out.data(), out.size()));
+    return out;
+  }
   // OccupancyMap::calcRange (occupancy_map.cpp:257-364); cos / sin from libm here, as the reference forms them
   double calcRange(double ox, double oy, double oa, double max_range)
   {

@@ -85,10 +85,12 @@ int bpf_synchronize(bpf_engine* e);
  * origin = origin_.x/.y (float), resolution_, max_distance_to_object_. */
 int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, int size_x, int size_y,
                   float origin_x, float origin_y, double resolution, double max_dist);
-/* Device-side replacement for OccupancyMap::updateDistancesLUT (occupancy_map.cpp:138-160):
- * exact Euclidean distance capped at max_dist, on the reference's (a,b)-integer
- * lattice.  NOT bit-identical to the reference's approximate brushfire; pass the
- * host LUT to bpf_map2d_set when parity with it matters. */
+/* The FAST, explicitly named alternative to OccupancyMap::updateDistancesLUT (occupancy_map.cpp:138-160): the exact
+ * Euclidean distance capped at max_dist, on the reference's (a,b)-integer lattice, built on the device in
+ * milliseconds.  NOT the reference's values: its brushfire is approximate (>= this, equal in > 99 % of the cells).
+ * The call that gives the reference's values is bpf_map2d_build_distances_lut_reference below, and that is what the
+ * host mirrors' `updateDistancesLUT` and the implicit build of bpf_planar_set_model_likelihood_field* use unless
+ * BPF_OPT_LUT_EXACT_EDT is set. */
 int bpf_map2d_build_distances_lut(bpf_engine* e, double max_dist);
 int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity);
 /* OccupancyMap::calcRange(ox, oy, oa, max_range) (occupancy_map.cpp:257-364) for n rays: the integer Bresenham
@@ -100,7 +102,8 @@ int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, cons
                          const double* max_range, int n, double* range_out);
 /* OccupancyMap::updateDistancesLUT exactly as the reference builds it (occupancy_map.cpp:138-252):
  * priority-queue brushfire on the host (std::priority_queue, so tie order matches a libstdc++
- * build of the reference), ~2 s for a 2000 x 2000 map.  Parity mode for SURVEY 8(f) next-3. */
+ * build of the reference), ~0.7 s for a 2000 x 2000 map, once per map as in the reference.  THE DEFAULT behind the
+ * reference-named calls. */
 int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist);
 
 /* ------------------------------------------------------------------ planar scanner
@@ -205,6 +208,10 @@ enum
                                * stream; 1: ONE launch with grid barriers between the levels when the stream fits one
                                * resident round of blocks (measured slower: 0.98 against 0.83 ms per step of the spread
                                * cloud -- every level is ~9 dependent round trips through the Infinity Cache either way) */
+  BPF_OPT_LUT_EXACT_EDT = 10, /* default 0: the implicit LUT build of bpf_planar_set_model_likelihood_field* (the reference calls
+                               * map_->updateDistancesLUT there, planar_scanner.cpp:74,91,112) is the reference's
+                               * brushfire on the host; 1 = the exact EDT on the device (milliseconds, values differ from
+                               * the reference's in < 1 % of the cells) */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.
@@ -555,11 +562,12 @@ typedef struct
   double ms[BPF_K_COUNT];          /* accumulated HIP-event time per kernel class */
   long long launches[BPF_K_COUNT];
 } bpf_profile;
-/* on = 1: every 4th launch of the dominant (scoring) kernel is timed by a pair of hipEvents attached to the
+/* on = 1: every 8th launch of the dominant (scoring) kernel is timed by a pair of hipEvents attached to the
  * dispatch itself (hipExtLaunchKernelGGL: the kernel's own start-to-end on the engine stream, which is what the
  * rocprofv3 kernel trace reports; a timed dispatch costs the update ~5 us, hence the sampling -- `launches` counts
  * the timed ones); on = 2: every scoring launch that way and every other kernel class bracketed by hipEventRecord
- * (costs host time per event, so not for timed regions); 0: off. */
+ * (costs host time per event, so not for timed regions); on = 3: as 1 but EVERY scoring launch (for scoring kernels
+ * of a millisecond or more, where the 5 us do not show); 0: off. */
 int bpf_profile_enable(bpf_engine* e, int on);
 int bpf_profile_reset(bpf_engine* e);
 int bpf_profile_get(bpf_engine* e, bpf_profile* out);

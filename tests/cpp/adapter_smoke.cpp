@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "badger_amcl_amd/adapter.hpp"
@@ -26,9 +27,14 @@ static std::vector<T> slurp(const char* path)
 
 int main(int argc, char** argv)
 {
-  if (argc < 9) { std::fprintf(stderr, "usage: cells lut samples ranges angles size out_weights out_resampled\n"); return 2; }
+  if (argc < 9) { std::fprintf(stderr, "usage: cells lut|- samples ranges angles size out_weights out_resampled [out_lut]\n"); return 2; }
   auto cells = slurp<int32_t>(argv[1]);
-  auto lut = slurp<float>(argv[2]);
+  // "-": no LUT is handed over; the reference-named calls build it (setModelLikelihoodField -> updateDistancesLUT,
+  // planar_scanner.cpp:74), which must give the reference's brushfire values
+  const bool own_lut = std::string(argv[2]) != "-";
+  std::vector<float> lut;
+  if (own_lut)
+    lut = slurp<float>(argv[2]);
   auto smp = slurp<double>(argv[3]);
   auto ranges = slurp<double>(argv[4]);
   auto angles = slurp<double>(argv[5]);
@@ -42,13 +48,21 @@ int main(int argc, char** argv)
   map->setOrigin(origin, origin);
   for (int i = 0; i < size * size; ++i)
     map->setCellState(i, (MapCellState)cells[i]);
-  map->setDistancesLUT(lut, 2.0);
+  if (own_lut)
+    map->setDistancesLUT(lut, 2.0);
 
   auto scanner = std::make_shared<PlanarScanner>(eng);
   scanner->init((int)ranges.size(), map);
   scanner->setModelLikelihoodField(0.95, 0.05, 0.2, 2.0);
   scanner->setMapFactors(0.95, 0.95, 0.3);
   scanner->setPlanarScannerPose({ 0.1, -0.05, 0.2 });
+  if (argc > 9)
+  {
+    auto built = map->getDistancesLUT();
+    FILE* fl = std::fopen(argv[9], "wb");
+    std::fwrite(built.data(), sizeof(float), built.size(), fl);
+    std::fclose(fl);
+  }
 
   auto pf = std::make_shared<ParticleFilter>(eng, 100, n, 0.0, 0.0, 85.0);
   pf->srand48(42);

@@ -81,6 +81,115 @@ def test_pmc_evidence_is_only_attached_to_the_workload_it_was_measured_on():
     assert 0.3 < ev["issue_frac"] < 1.1 and ev["hbm_measured_gbs"] > 0
     other = bench.pmc_evidence("lf", "converged", 0.0737, 5000, 181)
     assert other["traffic"] is None and "issue_frac" not in other
+    # ... and without a record NOTHING is claimed about what binds the kernel (it used to say "hbm")
+    assert other["bound"] is None
+    assert bench.pmc_evidence("lf", "spread", 0.12, 123456, 1081)["bound"] is None
+
+
+def test_plain_headline_detection_and_sub_records():
+    a = bench.parse_args([])
+    assert bench.is_plain_headline(a)
+    assert bench.is_plain_headline(bench.parse_args(["--gpus", "1", "--steps", "20", "--warmup", "5"]))
+    for argv in (["--config", "3"], ["--model", "beam"], ["--particles", "5000"], ["--cloud", "spread"],
+                 ["--resampler", "systematic"], ["--motion", "diff"], ["--beams", "181"]):
+        assert not bench.is_plain_headline(bench.parse_args(argv)), argv
+    cfgs = _baseline()["configs"]
+    s3 = bench.sub_args(a, config=3)
+    assert (s3.model, s3.particles, s3.beams, s3.map_size) == ("beam", 100000, 1081, 2000)
+    assert bench.workload_name(s3, 1) == cfgs[2].replace("×", "x").split(", 1x")[0].replace("2000x2000", "2000x2000")
+    s5 = bench.sub_args(a, config=5)
+    assert (s5.model, s5.particles) == ("cloud3d", 200000)
+    s1 = bench.sub_args(a, config=1)
+    assert (s1.model, s1.particles, s1.beams, s1.map_size) == ("lf", 5000, 181, 400)
+    # configs[3] as worded: 1 M particles TOTAL whatever N is
+    for world in (1, 2, 4, 8):
+        st = bench.sub_args(a, strong_total=bench.STRONG_TOTAL)
+        per = [bench.STRONG_TOTAL * (r + 1) // world - bench.STRONG_TOTAL * r // world for r in range(world)]
+        assert sum(per) == 1000000
+        st.particles = per[0]
+        name = bench.workload_name(st, world)
+        assert "1M particles sharded %dxMI355X" % world in name and "1000000 particles TOTAL" in name
+        assert "%d per GPU" % (1000000 // world) in name
+    assert "1M particles sharded 8" in cfgs[3]
+    # a sub-record keeps the graded fields
+    line = {"metric": "m", "value": 1.0, "ms_per_step": 2.0, "roofline": {"frac": 0.5}, "cpu_baseline": {"value": 3},
+            "config": {"workload": "w"}, "junk": 1}
+    sub = bench.sub_record(line)
+    assert set(sub) == {"metric", "value", "ms_per_step", "roofline", "cpu_baseline", "config"}
+
+
+def test_cpu_sample_is_bounded_by_the_budget():
+    # headline: one step of the whole set fits 12 s at the oracle's pace; a 4 s budget of the beam model does not
+    assert bench.cpu_sample_particles("lf", 100000, 1081, 12.0) == 100000
+    n3 = bench.cpu_sample_particles("beam", 100000, 1081, 4.0)
+    assert 5000 < n3 < 40000
+    assert bench.cpu_sample_particles("lf", 1000000, 1081, 4.0) < 200000
+    assert bench.cpu_sample_particles("lf", 5000, 181, 4.0) == 5000
+    assert 100 <= bench.cpu_sample_particles("cloud3d", 200000, 65536, 4.0) < 2000
+
+
+def test_multi_gpu_fields_shape():
+    """(a)-(c) of the N > 1 line: exchange_ms carries both exchanges, the self-test verdict and the communicator
+    size are there, and a gloo rehearsal does not pass for RCCL."""
+    assert bench.multi_gpu_fields(None, None, None, None) == {}
+    ex = {"mailbox": 0.14, "collective": 0.17}
+    f = bench.multi_gpu_fields("nccl", 8, "pass", ex)
+    assert f["rccl_ranks"] == 8 and f["mailbox_selftest"] == "pass" and f["exchange_ms"] == ex
+    assert "RCCL" in f["collective_is"] and "RCCL" in f["exchange_ms_is"]
+    g = bench.multi_gpu_fields("gloo", 2, "fail: window self-test", {"mailbox": None, "collective": 0.2})
+    assert g["rccl_ranks"] == 0 and "rehearsal" in g["collective_is"] and g["mailbox_selftest"].startswith("fail")
+    for k in ("exchange_ms", "mailbox_selftest", "rccl_ranks"):
+        assert k in bench.SUB_KEYS
+    for k in ("roofline", "cpu_baseline", "config", "ms_per_step", "value"):
+        assert k in bench.SUB_KEYS
+
+
+def test_a_stage_that_exceeds_its_bound_names_itself_and_exits_nonzero():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Stage('mailbox connect round', 0.3):\n    time.sleep(20)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 124 and r.stdout == b""
+    assert b"stage 'mailbox connect round' exceeded" in r.stderr and r.stderr.count(b"\n") == 1
+    # a stage that fails names itself too, and the error still goes up
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "with bench.Stage('engine set-up', 5):\n    raise RuntimeError('boom')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode != 0 and b"stage 'engine set-up' failed" in r.stderr and b"boom" in r.stderr
+
+
+def _parked_rank(rank, world, port, q):
+    import datetime
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    ctx = bench.Ctx()
+    ctx.dist = dist
+    ctx.host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
+    t0 = time.perf_counter()
+    if rank == 0:
+        time.sleep(1.5)  # rank 0's CPU baseline
+    ctx.host_barrier(30)
+    q.put((rank, time.perf_counter() - t0))
+    dist.destroy_process_group()
+
+
+def test_ranks_are_parked_on_the_host_while_rank_0_times_the_cpu_baseline():
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_parked_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[1] >= 1.0  # rank 1 waited for rank 0's CPU leg
 
 
 def _run(argv, env_extra, timeout=240):

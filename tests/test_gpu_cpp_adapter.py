@@ -50,3 +50,32 @@ def test_adapter_run_matches_oracle(tmp_path, orc):
     got_r = np.fromfile(out_r, dtype=np.float64).reshape(-1, 4)
     assert (m, leaf, conv) == (out.sample_count, out.leaf_count, out.converged)
     assert np.array_equal(got_r[:, :3], opf.samples[:m, :3])
+
+
+@pytest.mark.gpu
+def test_adapter_default_lut_is_the_reference_brushfire(tmp_path, orc):
+    """No LUT handed over: the reference-named call sequence (setModelLikelihoodField -> map->updateDistancesLUT,
+    planar_scanner.cpp:74, occupancy_map.cpp:138-252) must leave the oracle's brushfire values behind, bit for bit,
+    and the weights that follow from them."""
+    exe = _compile(tmp_path)
+    sc = Scenario(orc, size=200, n=1500, beams=91, cloud="mixture")
+    rng = np.random.default_rng(9)
+    sc.cells[rng.random(sc.cells.shape) < 0.002] = 1   # scattered obstacles: many equidistant ties
+    sc.omap = orc.OccupancyMap(sc.cells, sc.res, sc.origin)
+    sc.lut = sc.omap.update_distances_lut(2.0)
+    paths = {}
+    for name, arr in (("cells", sc.cells.astype(np.int32)), ("samples", sc.samples), ("ranges", sc.ranges),
+                      ("angles", sc.angles)):
+        paths[name] = str(tmp_path / (name + ".bin"))
+        np.ascontiguousarray(arr).tofile(paths[name])
+    out_w, out_r, out_l = str(tmp_path / "w.bin"), str(tmp_path / "r.bin"), str(tmp_path / "l.bin")
+    subprocess.run([str(exe), paths["cells"], "-", paths["samples"], paths["ranges"], paths["angles"], "200", out_w,
+                    out_r, out_l], capture_output=True, text=True, check=True)
+    got_l = np.fromfile(out_l, dtype=np.float32)
+    assert np.array_equal(got_l, np.asarray(sc.lut, dtype=np.float32).reshape(-1))
+    opf = orc.ParticleFilter(100, 1500, 0.0, 0.0, 85.0, seed=42)
+    opf.set_samples(sc.samples)
+    p = sc.oracle_planar(91, "lf")
+    opf.update_sensor(lambda s, c: sc.oracle_apply(p, s, c))
+    got_w = np.fromfile(out_w, dtype=np.float64).reshape(-1, 4)
+    assert rel_err(got_w[:, 3], opf.samples[:1500, 3]).max() <= 1e-9

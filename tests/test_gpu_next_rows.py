@@ -171,6 +171,46 @@ def test_reference_brushfire_lut_is_bit_identical(engine, orc):
         assert np.array_equal(got.reshape(-1), np.asarray(want, dtype=np.float32).reshape(-1))
 
 
+def test_reference_named_calls_give_the_reference_lut_by_default(engine, orc):
+    """OccupancyMap.updateDistancesLUT and the implicit build inside setModelLikelihoodField (the reference calls
+    map_->updateDistancesLUT there, planar_scanner.cpp:74) leave the brushfire's values behind, bit for bit; the
+    exact EDT is only what its own name (updateDistancesLUTExact / BPF_OPT_LUT_EXACT_EDT) asks for."""
+    import badger_amcl_amd as bpf
+    cells, origin = synth.make_map(240)
+    rng = np.random.default_rng(77)
+    cells[rng.random(cells.shape) < 0.002] = 1
+    want = np.asarray(orc.OccupancyMap(cells, 0.05, origin).update_distances_lut(1.3), dtype=np.float32).reshape(-1)
+
+    def fresh():
+        m = bpf.OccupancyMap(engine, 0.05)
+        m.setCells(cells)
+        m.setOrigin(origin)
+        return m
+
+    m = fresh()
+    m.updateDistancesLUT(1.3)
+    assert np.array_equal(m.getDistancesLUT().reshape(-1), want)
+    # implicit: no LUT yet for this max distance when the model is set
+    m = fresh()
+    sc = bpf.PlanarScanner(engine)
+    sc.init(30, m)
+    sc.setModelLikelihoodField(0.95, 0.05, 0.2, 1.3)
+    assert np.array_equal(m.getDistancesLUT().reshape(-1), want)
+    # the explicitly named fast builders: exact EDT, never above the brushfire, different somewhere on this map
+    m = fresh()
+    m.updateDistancesLUTExact(1.3)
+    edt = m.getDistancesLUT().reshape(-1)
+    assert np.all(edt <= want) and np.mean(edt == want) > 0.97 and not np.array_equal(edt, want)
+    engine.set_option(bpf.pf.OPT_LUT_EXACT_EDT, 1)
+    try:
+        m = fresh()
+        sc.init(30, m)
+        sc.setModelLikelihoodField(0.95, 0.05, 0.2, 1.3)
+        assert np.array_equal(m.getDistancesLUT().reshape(-1), edt)
+    finally:
+        engine.set_option(bpf.pf.OPT_LUT_EXACT_EDT, 0)
+
+
 @pytest.mark.parametrize("host", [0, 1])
 def test_octomap_lut_builder_matches_oracle(engine, orc, host):
     """bpf_map3d_build_distances_lut == OctoMap::updateDistancesLUT (oracle restatement): same column

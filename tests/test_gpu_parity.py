@@ -428,7 +428,7 @@ def test_device_distance_lut_is_exact_edt(engine, orc):
     m = bpf.OccupancyMap(engine, sc_.res)
     m.setCells(sc_.cells)
     m.setOrigin(sc_.origin)
-    m.updateDistancesLUT(0.5)
+    m.updateDistancesLUTExact(0.5)
     got = m.getDistancesLUT()
     occ = np.argwhere(sc_.cells == 1)
     ys, xs = np.mgrid[0:200, 0:200]
