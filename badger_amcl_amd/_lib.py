@@ -78,6 +78,10 @@ SIGNATURES = {
     "bpf_pf_get_cluster": (C.c_int, [_vp, C.c_int, C.POINTER(Cluster)]),
     "bpf_pf_get_max_weight_pose": (C.c_int, [_vp, _dp, _dp]),
     "bpf_map2d_build_distances_lut_reference": (C.c_int, [_vp, C.c_double]),
+    "bpf_host_buffer_register": (C.c_int, [_vp, C.c_void_p, C.c_size_t]),
+    "bpf_host_buffer_unregister": (C.c_int, [_vp, C.c_void_p]),
+    "bpf_host_buffer_is_registered": (C.c_int, [_vp, C.c_void_p, C.c_size_t]),
+    "bpf_seam_last_plan": (C.c_int, [_vp, _ip, _ip]),
     "bpf_wire_laserscan_to_planar": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_double,
                                                C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]),
     "bpf_wire_scan_angle_stats": (C.c_int, [C.c_double, C.c_double, _dp, _dp, _dp]),

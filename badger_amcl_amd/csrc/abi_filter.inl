@@ -93,6 +93,7 @@ int bpf_pf_get_rng_state(const bpf_engine* e, uint64_t* state48)
 namespace
 {
 int finish_init(bpf_engine* e, int n);  // abi_motion.inl
+int ensure_set_tree(bpf_engine* e);     // abi_motion.inl
 }
 
 int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, int leaf_count)
@@ -104,6 +105,7 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
   if (sample_count <= 0 || sample_count > e->max_samples)
     return e->fail(BPF_ERR_CAPACITY, "sample_count outside (0, max_samples]");
   HIPCHK(e, hipSetDevice(e->device));
+  (void)host_buffer_pinned(e, const_cast<double*>(samples), (size_t)sample_count * sizeof(double4));
   int rc = upload_samples(e, samples, sample_count, e->sets[e->cur]);
   if (rc != BPF_OK)
     return rc;
@@ -115,6 +117,8 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
   HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
   e->converged = 0;
   e->converged_pending = false;
+  e->fused_partials = 0;
+  e->tree_pending = false;
   if (leaf_count >= 0)
   {
     e->leaf_count = leaf_count;
@@ -122,12 +126,11 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
   }
   else
   {
-    // the set's histogram tree, as the reference builds it when a set is created: on the device for large sets
-    // (0.5 ms instead of ~2 ms of host insertion for 100 k samples), host otherwise -- the same as after
-    // initWithGaussian / initWithPoseFn
-    rc = finish_init(e, sample_count);
-    if (rc != BPF_OK)
-      return rc;
+    // the set's histogram tree, as the reference builds it when a set is created (on the device for large sets, as
+    // after initWithGaussian / initWithPoseFn), is built when it is first needed: ensure_set_tree
+    e->hist_matches_set = false;
+    e->leaf_count = e->bin_count = -1;
+    e->tree_pending = true;
   }
   HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller's buffer is only the call's
   return BPF_OK;
@@ -148,9 +151,18 @@ int bpf_pf_get_samples(bpf_engine* e, double* samples_out, int capacity, int* sa
   hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->sets[e->cur].dev(),
                      e->d_aos.p, n);
   HIPCHK(e, hipGetLastError());
-  HIPCHK(e, hipMemcpyAsync(e->h_aos.p, e->d_aos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  std::memcpy(samples_out, e->h_aos.p, (size_t)n * sizeof(double4));
+  if (host_buffer_pinned(e, samples_out, (size_t)n * sizeof(double4)))
+  {
+    // a registered buffer of the caller: the copy engine writes it directly
+    HIPCHK(e, hipMemcpyAsync(samples_out, e->d_aos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
+  else
+  {
+    HIPCHK(e, hipMemcpyAsync(e->h_aos.p, e->d_aos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    std::memcpy(samples_out, e->h_aos.p, (size_t)n * sizeof(double4));
+  }
   if (sample_count_out)
     *sample_count_out = n;
   return BPF_OK;
@@ -161,6 +173,11 @@ int bpf_pf_snapshot(bpf_engine* e)
   if (!e || !e->have_pf)
     return BPF_ERR_INVALID_ARGUMENT;
   HIPCHK(e, hipSetDevice(e->device));
+  {
+    const int rct = ensure_set_tree(e);
+    if (rct != BPF_OK)
+      return rct;
+  }
   const size_t n = (size_t)e->sample_count;
   HIPCHK(e, e->snap.reserve(n));
   SampleSet& s = e->sets[e->cur];
@@ -184,6 +201,7 @@ int bpf_pf_restore(bpf_engine* e)
                      e->snap.dev(), n);
   HIPCHK(e, hipGetLastError());
   e->sample_count = e->snap_count;
+  e->tree_pending = false;
   e->leaf_count = e->snap_leaf;
   e->bin_count = e->snap_bins;
   e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
@@ -299,7 +317,15 @@ int bpf_pf_update_resample(bpf_engine* e)
   }
   e->w_diff_last = w_diff;
   SampleSet& a = e->sets[e->cur];
-  int rc = build_cdf(e, a.w.p, e->sample_count);
+  int rc = BPF_OK;
+  if (e->resample_model == BPF_RESAMPLE_SYSTEMATIC)
+  {
+    rc = ensure_set_tree(e);  // its sample count comes from the current set's leaf count (particle_filter.cpp:276)
+    if (rc != BPF_OK)
+      return rc;
+  }
+  e->tree_pending = false;  // the multinomial resampler builds the new set's tree from its draws
+  rc = build_cdf(e, a.w.p, e->sample_count);
   if (rc != BPF_OK)
     return rc;
   e->kld_device_used = false;
@@ -357,7 +383,10 @@ int bpf_pf_get_state(bpf_engine* e, bpf_pf_state* out)
   if (!e->have_pf)
     return e->fail(BPF_ERR_NOT_CONFIGURED, "bpf_pf_create first");
   HIPCHK(e, hipSetDevice(e->device));
-  int rc = fetch_scalars(e);
+  int rc = ensure_set_tree(e);
+  if (rc != BPF_OK)
+    return rc;
+  rc = fetch_scalars(e);
   if (rc != BPF_OK)
     return rc;
   if (e->h_flags.p[0] != 0 && e->last_status == BPF_OK)

@@ -1,0 +1,137 @@
+// C-ABI: caller-owned host buffers (the reference keeps its particles in a host std::vector<PFSample> that is
+// allocated once, particle_filter.cpp:62-89, and hands it to the sensor model every cycle).
+// ---------------------------------------------------------------------- host buffers
+// A pageable buffer crosses PCIe through the runtime's bounce buffers at ~13 GB/s with the calling thread doing the
+// staging copy; a buffer pinned with hipHostRegister is read by the copy engine directly (~50 GB/s, no host work).
+// Registration costs about a millisecond, so it is done ONCE per buffer and kept.  It is the OWNER's statement that
+// the memory stays allocated until bpf_host_buffer_unregister / bpf_destroy: the driver follows a registered range
+// by virtual address, and a range that has been freed (or freed and re-allocated) under a live registration makes
+// the next DMA fault.  That is why the engine does not cache registrations by pointer on its own
+// (BPF_OPT_HOST_AUTO_REGISTER is the caller's explicit promise for every buffer it hands over).
+namespace
+{
+bpf_engine::HostReg* host_reg_find(bpf_engine* e, const void* ptr, size_t bytes)
+{
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  for (auto& r : e->host_regs)
+    if (a >= r.base && a + bytes <= r.base + r.bytes)
+      return &r;
+  return nullptr;
+}
+
+int host_reg_add(bpf_engine* e, void* ptr, size_t bytes, bool automatic)
+{
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  // a range that overlaps an older registration without lying inside it: the buffer was re-allocated or grew
+  for (size_t i = 0; i < e->host_regs.size();)
+  {
+    auto& r = e->host_regs[i];
+    if (a < r.base + r.bytes && r.base < a + bytes)
+    {
+      if (!(automatic && r.automatic))
+        return e->fail(BPF_ERR_INVALID_ARGUMENT, "host buffer overlaps a registered range");
+      (void)hipHostUnregister(reinterpret_cast<void*>(r.base));
+      e->host_regs.erase(e->host_regs.begin() + (long)i);
+    }
+    else
+      ++i;
+  }
+  if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return e->fail(BPF_ERR_HIP, "hipHostRegister refused the buffer");
+  }
+  e->host_regs.push_back(bpf_engine::HostReg{ a, bytes, automatic });
+  return BPF_OK;
+}
+
+// true when [ptr, ptr + bytes) may be handed to the copy engine as pinned memory
+bool host_buffer_pinned(bpf_engine* e, void* ptr, size_t bytes)
+{
+  if (host_reg_find(e, ptr, bytes))
+    return true;
+  if (!e->host_auto_register || bytes < (size_t)64 * 1024)
+    return false;
+  return host_reg_add(e, ptr, bytes, true) == BPF_OK;
+}
+
+void host_buffers_release(bpf_engine* e)
+{
+  for (auto& r : e->host_regs)
+    (void)hipHostUnregister(reinterpret_cast<void*>(r.base));
+  e->host_regs.clear();
+  for (auto ev : e->seam_ev)
+    (void)hipEventDestroy(ev);
+  e->seam_ev.clear();
+  if (e->copy_up)
+    (void)hipStreamDestroy(e->copy_up);
+  e->copy_up = nullptr;
+}
+
+int seam_resources(bpf_engine* e)
+{
+  if (e->copy_up)
+    return BPF_OK;
+  HIPCHK(e, hipStreamCreateWithFlags(&e->copy_up, hipStreamNonBlocking));
+  e->seam_ev.resize((size_t)kSeamMaxChunks, nullptr);
+  for (auto& ev : e->seam_ev)
+    HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCHK(e, e->d_seam_partials.reserve((size_t)kSeamMaxChunks * kSeamMaxBlocks));
+  HIPCHK(e, e->h_seam_flags.reserve((size_t)kSeamMaxChunks));
+  HIPCHK(e, e->h_seam_totals.reserve((size_t)kSeamMaxChunks));
+  for (int i = 0; i < kSeamMaxChunks; ++i)
+    e->h_seam_flags.p[i] = 0ull;
+  return BPF_OK;
+}
+}  // namespace
+
+int bpf_host_buffer_register(bpf_engine* e, void* ptr, size_t bytes)
+{
+  if (!e || !ptr || bytes == 0)
+    return e ? e->fail(BPF_ERR_INVALID_ARGUMENT, "host buffer: null or empty") : BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (bpf_engine::HostReg* r = host_reg_find(e, ptr, bytes))
+  {
+    r->automatic = false;  // now the owner's
+    return BPF_OK;
+  }
+  return host_reg_add(e, ptr, bytes, false);
+}
+
+int bpf_host_buffer_unregister(bpf_engine* e, void* ptr)
+{
+  if (!e || !ptr)
+    return BPF_ERR_INVALID_ARGUMENT;
+  HIPCHK(e, hipSetDevice(e->device));
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  for (size_t i = 0; i < e->host_regs.size(); ++i)
+    if (e->host_regs[i].base == a)
+    {
+      // nothing of the engine may still be reading or writing it
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      if (e->copy_up)
+        HIPCHK(e, hipStreamSynchronize(e->copy_up));
+      HIPCHK(e, hipHostUnregister(ptr));
+      e->host_regs.erase(e->host_regs.begin() + (long)i);
+      return BPF_OK;
+    }
+  return e->fail(BPF_ERR_INVALID_ARGUMENT, "host buffer: not a registered base address");
+}
+
+int bpf_host_buffer_is_registered(bpf_engine* e, const void* ptr, size_t bytes)
+{
+  if (!e || !ptr)
+    return 0;
+  return host_reg_find(e, ptr, bytes) != nullptr ? 1 : 0;
+}
+
+int bpf_seam_last_plan(bpf_engine* e, int* chunks_out, int* pinned_out)
+{
+  if (!e)
+    return BPF_ERR_INVALID_ARGUMENT;
+  if (chunks_out)
+    *chunks_out = e->last_seam_chunks;
+  if (pinned_out)
+    *pinned_out = e->last_seam_registered ? 1 : 0;
+  return BPF_OK;
+}

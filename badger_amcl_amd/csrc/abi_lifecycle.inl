@@ -42,6 +42,7 @@ void bpf_destroy(bpf_engine* e)
   }
   collective_release(e);
   mailbox_release(e);
+  host_buffers_release(e);
   if (e->targets_read)
     (void)hipEventDestroy(e->targets_read);
   for (auto ev : e->ev_start)

@@ -131,6 +131,11 @@ int update_action(bpf_engine* e, const double pose[3], const double delta[3], co
   if (global_first < 0 || global_first + n > global_count)
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "shard range outside the global set");
   HIPCHK(e, hipSetDevice(e->device));
+  {
+    const int rct = ensure_set_tree(e);  // the tree belongs to the poses the set was created with
+    if (rct != BPF_OK)
+      return rct;
+  }
   const MotionModelDev M = motion_constants(e, pose, delta, absolute_motion);
   SampleSet& src = e->sets[e->cur];
   SampleSet& dst = e->sets[e->cur ^ 1];
@@ -151,6 +156,20 @@ int update_action(bpf_engine* e, const double pose[3], const double delta[3], co
   return BPF_OK;
 }
 
+int build_set_tree(bpf_engine* e, int n);
+
+// A set adopted from host memory (bpf_pf_set_samples) gets its histogram tree only when somebody asks for what the
+// tree is for -- the leaf count (get_state, snapshot, the systematic resampler) -- or before the poses move
+// (the reference builds the tree when the set is created, so it must be the tree of THESE poses).  A cycle that
+// uploads the set, updates and resamples with the multinomial resampler never needs it: the resample builds the new
+// set's tree from its draws.
+int ensure_set_tree(bpf_engine* e)
+{
+  if (!e->tree_pending)
+    return BPF_OK;
+  return build_set_tree(e, e->sample_count);
+}
+
 // what initWithGaussian / initWithPoseFn leave besides the poses (particle_filter.cpp:126-131,157-162): the
 // histogram tree of the set (leaf / bin counts), w_slow = w_fast = 0, converged = false
 int finish_init(bpf_engine* e, int n)
@@ -164,6 +183,14 @@ int finish_init(bpf_engine* e, int n)
   HIPCHK(e, hipMemsetAsync(e->d_scalars.p, 0, sizeof(FilterScalars), e->stream));
   e->converged = 0;
   e->converged_pending = false;
+  return build_set_tree(e, n);
+}
+
+// the histogram tree of the current set (PFKDTree of every sample, pf_kdtree.cpp:49-56): leaf and bin counts
+int build_set_tree(bpf_engine* e, int n)
+{
+  SampleSet& s = e->sets[e->cur];
+  e->tree_pending = false;
   HIPCHK(e, e->d_keys.reserve((size_t)n * 3));
   hipLaunchKernelGGL(k_set_keys, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, s.dev(), n, e->d_keys.p);
   HIPCHK(e, hipGetLastError());

@@ -383,6 +383,7 @@ int bpf_shard_adopt_dev(bpf_engine* e, const void* x_dev, const void* y_dev, con
   }
   e->cur ^= 1;
   e->sample_count = count;
+  e->tree_pending = false;
   e->leaf_count = leaf_count;
   e->bin_count = bin_count;
   e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
@@ -408,6 +409,7 @@ int bpf_shard_tail_small_dev(bpf_engine* e, const void* x_all_dev, const void* y
   HIPCHK(e, hipGetLastError());
   e->cur ^= 1;
   e->sample_count = hi - lo;
+  e->tree_pending = false;
   e->leaf_count = leaf_count;
   e->bin_count = bin_count;
   e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
@@ -510,6 +512,7 @@ int shard_stop_block(bpf_engine* e, const long long* window, int stride, int cou
   *bins_out = r5[2];
   e->cur ^= 1;
   e->sample_count = hi - lo;
+  e->tree_pending = false;
   e->leaf_count = r5[1];
   e->bin_count = r5[2];
   e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
@@ -906,6 +909,10 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->lut_host = value != 0;
   else if (option == BPF_OPT_LUT_EXACT_EDT)
     e->lut_exact_edt = value != 0;
+  else if (option == BPF_OPT_HOST_AUTO_REGISTER)
+    e->host_auto_register = value != 0;
+  else if (option == BPF_OPT_SEAM_CHUNKS)
+    e->seam_chunks = value < 0 ? 0 : (value > kSeamMaxChunks ? kSeamMaxChunks : value);
   else if (option == BPF_OPT_KLD_PERSISTENT)
     e->kld_persistent = value != 0;
   else if (option == BPF_OPT_STATS_HOST)

@@ -46,8 +46,10 @@ namespace
 {
 void mailbox_release(bpf_engine* e);     // abi_mailbox.inl
 void collective_release(bpf_engine* e);  // abi_bootstrap.inl
+void host_buffers_release(bpf_engine* e);  // abi_hostbuf.inl
 }
 #include "abi_lifecycle.inl"
+#include "abi_hostbuf.inl"
 #include "abi_map2d.inl"
 #include "abi_planar.inl"
 #include "abi_filter.inl"

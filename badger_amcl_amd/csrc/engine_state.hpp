@@ -11,6 +11,8 @@ constexpr int kMaxBeams = 4096;     // beams staged in LDS per launch
 constexpr double kMaxRayCells = 32760.0;
 constexpr int kTableLdsMax = 2048;  // table entries that still go to LDS
 constexpr int kEventPool = 8192;
+constexpr int kSeamMaxChunks = 8;
+constexpr int kSeamMaxBlocks = 4096;
 
 // Device / pinned buffers free themselves with the engine (bpf_destroy selects the device first).
 template <typename T>
@@ -379,6 +381,27 @@ struct bpf_engine
   long long stats_epoch = -1;   // value of set_epoch the statistics were computed for
   long long set_epoch = 0;      // bumped whenever the current set's poses / weights change
   bool hist_matches_set = false;
+
+  // ---- host-buffer seam (abi_hostbuf.inl, abi_planar.inl): caller memory pinned with hipHostRegister, the copy
+  // streams and events of the pipelined applyModelToSampleSet, the lazily built histogram tree of an adopted set
+  struct HostReg
+  {
+    uintptr_t base;
+    size_t bytes;
+    bool automatic;  // made by BPF_OPT_HOST_AUTO_REGISTER, not by bpf_host_buffer_register
+  };
+  std::vector<HostReg> host_regs;
+  bool host_auto_register = false;  // BPF_OPT_HOST_AUTO_REGISTER
+  int seam_chunks = 0;              // BPF_OPT_SEAM_CHUNKS (0 = by size, 1 = the plain sequence)
+  hipStream_t copy_up = nullptr;    // the uploads of the pipelined seam
+  std::vector<hipEvent_t> seam_ev;  // [kSeamMaxChunks]: chunk uploaded
+  DevBuf<double> d_seam_partials;   // [kSeamMaxChunks][kSeamMaxBlocks] block partials of the chunks' launches
+  PinnedBuf<unsigned long long> h_seam_flags;  // [kSeamMaxChunks]: chunk c scored (the launch's generation)
+  PinnedBuf<double> h_seam_totals;  // [kSeamMaxChunks]: weight total of chunk c
+  unsigned long long seam_generation = 0;
+  int last_seam_chunks = 0;         // chunks the last applyModelToSampleSet used (0: the plain sequence)
+  bool last_seam_registered = false;
+  bool tree_pending = false;        // the current set's histogram tree (leaf / bin counts) has not been built yet
 
   // ---- profiling
   bool profiling = false;

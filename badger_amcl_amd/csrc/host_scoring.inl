@@ -152,8 +152,20 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
   return BPF_OK;
 }
 
+// aos != nullptr: the n particles are still 32-byte records at `aos` (device memory); the prep launch unpacks them into
+// `p` as it goes (k_field_prep_aos) -- the chunks of the pipelined host-buffer seam (abi_planar.inl).
+// host_out != nullptr: the HOST_OUT form of the scoring kernel (weights to a pinned array as well, a done word).
+struct FieldHostOut
+{
+  double* w_host;
+  double* total_host;
+  double* partials;  // >= blocks of the launch
+  unsigned long long* flag;
+  unsigned long long value;
+};
 int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldScan& fs, int* obs_count,
-                 int skip_level, bool want_partials = false)
+                 int skip_level, bool want_partials = false, const double4* aos = nullptr,
+                 const FieldHostOut* host_out = nullptr)
 {
   FieldScoreArgs A{};
   A.p = p;
@@ -186,6 +198,10 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   const int prep_blocks = blocks_for(n, 256);
   HIPCHK(e, e->d_prep.reserve((size_t)n));
   HIPCHK(e, e->d_prep_stats.reserve((size_t)prep_blocks * kPrepStats));
+  if (host_out != nullptr)
+  {
+    A.w_host = host_out->w_host;
+  }
   {
     const int n16 = (int)((fs.bytes + 15) / 16);
     const bool ride = fs.copy_pending && n16 <= prep_blocks * 256;
@@ -193,7 +209,10 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
       HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs.bytes, hipMemcpyHostToDevice, e->stream));
     ProfScope pa(e, BPF_K_SCORE_AUX);
     const uint4* src = ride ? reinterpret_cast<const uint4*>(s->host.p) : static_cast<const uint4*>(nullptr);
-    if (e->window_enabled)
+    if (aos != nullptr)
+      hipLaunchKernelGGL(k_field_prep_aos, dim3(prep_blocks), dim3(256), 0, e->stream, aos, p, n, e->map, A.sp_x, A.sp_y,
+                         A.sp_th, e->d_prep.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
+    else if (e->window_enabled)
       hipLaunchKernelGGL(k_field_prep<true>, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
                          A.sp_th, e->d_prep.p, e->d_prep_stats.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
     else
@@ -204,9 +223,12 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   // One resident round: blocks per CU = what registers, LDS and the SGPR rule admit (the occupancy
   // API can over-report by one block for SGPR-heavy kernels: MI355X_MICROARCH.md, residency).
   int api_blocks = 0;
+  if (host_out != nullptr && (count_only || !table_lds))
+    return e->fail(BPF_ERR_UNSUPPORTED, "host-out scoring kernel: table-in-LDS scoring form only");
   const void* kfn = count_only ? reinterpret_cast<const void*>(&k_score_field<true, false>)
-                               : (table_lds ? reinterpret_cast<const void*>(&k_score_field<false, true>)
-                                            : reinterpret_cast<const void*>(&k_score_field<false, false>));
+                               : (host_out != nullptr ? reinterpret_cast<const void*>(&k_score_field<false, true, true>)
+                                  : (table_lds ? reinterpret_cast<const void*>(&k_score_field<false, true>)
+                                               : reinterpret_cast<const void*>(&k_score_field<false, false>)));
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, kfn, 256, lds) != hipSuccess || api_blocks < 1)
     api_blocks = 1;
   const int per_cu = std::max(1, std::min(api_blocks, 6));
@@ -232,7 +254,9 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
     }
     grid = e->n_cu * per_cu;
   }
-  A.block_partials = nullptr;
+  if (host_out != nullptr && grid > kSeamMaxBlocks)
+    return e->fail(BPF_ERR_CAPACITY, "host-out scoring launch: more blocks than the partials buffer holds");
+  A.block_partials = host_out != nullptr ? host_out->partials : nullptr;
   A.skip_if_set = nullptr;
   e->last_used_window_path = false;
   if (want_partials && !count_only)
@@ -300,6 +324,12 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   }
   if (count_only)
     LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<true, false>), dim3(grid), dim3(256), lds, A);
+  else if (host_out != nullptr)
+  {
+    LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true, true>), dim3(grid), dim3(256), lds, A);
+    hipLaunchKernelGGL(k_seam_done, dim3(1), dim3(256), 0, e->stream, (const double*)host_out->partials, grid,
+                       host_out->total_host, host_out->flag, host_out->value);
+  }
   else if (table_lds)
     LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true>), dim3(grid), dim3(256), lds, A);
   else
@@ -308,14 +338,19 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   return BPF_OK;
 }
 
-int sum_into_slot(bpf_engine* e, const double* v, int n, int slot, int update_averages, int n_samples)
+// dst: where the scalars live (default: the engine's device block; the host-buffer seam passes the pinned host copy so
+// that the total needs no copy behind it)
+int sum_into_slot(bpf_engine* e, const double* v, int n, int slot, int update_averages, int n_samples,
+                  FilterScalars* dst = nullptr, unsigned long long* done_flag = nullptr,
+                  unsigned long long done_value = 0ull)
 {
   const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
   HIPCHK(e, e->d_partials.reserve((size_t)nb));
   ProfScope ps(e, BPF_K_REDUCE);
   hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, v, n, e->d_partials.p);
-  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_partials.p, nb, e->d_scalars.p,
-                     slot, update_averages, n_samples, e->alpha_slow, e->alpha_fast);
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(BPF_RED_BLOCK), 0, e->stream, e->d_partials.p, nb,
+                     dst ? dst : e->d_scalars.p, slot, update_averages, n_samples, e->alpha_slow, e->alpha_fast,
+                     done_flag, done_value);
   HIPCHK(e, hipGetLastError());
   return BPF_OK;
 }
@@ -399,9 +434,12 @@ int score_planar_beamskip_finish(bpf_engine* e, ParticlesDev p, int n, long long
 // weights un-normalised.  set_converged feeds the prob model's beam-skip switch.  defer_beamskip_pass2: stop
 // after the counting pass of beam skipping (e->skip_pending is then set) so that a sharded driver can sum the
 // counts over the shards before score_planar_beamskip_finish.
+// aos != nullptr: the n particles are still 32-byte records at `aos` (device memory, as the copy engine left them);
+// they are unpacked into `p` on the way (by the prep launch of the likelihood-field family, by a launch of its own
+// for the other forms).
 int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const double* ranges,
                  const double* angles, int rc, double range_max, bool* forced_zero, bool want_partials = false,
-                 bool defer_beamskip_pass2 = false)
+                 bool defer_beamskip_pass2 = false, const double4* aos = nullptr)
 {
   *forced_zero = false;
   e->fused_partials = 0;
@@ -416,6 +454,13 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
     return e->fail(BPF_ERR_INVALID_ARGUMENT, "empty scan or sample set");
   const PlanarModel& pm = e->pm;
   e->evals_last = 0;
+  if (aos != nullptr && (pm.model == BPF_MODEL_BEAM ||
+                         (pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && pm.do_beamskip && set_converged)))
+  {
+    hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, aos, p, n);
+    HIPCHK(e, hipGetLastError());
+    aos = nullptr;
+  }
 
   if (pm.model == BPF_MODEL_BEAM)
   {
@@ -518,7 +563,7 @@ int score_planar(bpf_engine* e, ParticlesDev p, int n, int set_converged, const 
   const bool beamskip = pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && pm.do_beamskip && set_converged;
   if (!beamskip)
   {
-    rcode = launch_field(e, p, n, s, fs, nullptr, 0, want_partials);
+    rcode = launch_field(e, p, n, s, fs, nullptr, 0, want_partials, aos);
     if (rcode != BPF_OK)
       return rcode;
     return release_slot(e, s);

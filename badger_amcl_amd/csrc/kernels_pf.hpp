@@ -87,9 +87,13 @@ struct FilterScalars
 
 // Folds the partials; when update_averages != 0 also applies particle_filter.cpp:237-256:
 // w_avg = total / n, first-time assignment or exponential update of w_slow / w_fast.
+// done_flag != nullptr (the host-buffer seam: sc is then the pinned host block): the word the host polls is
+// published behind the total.
 __global__ __launch_bounds__(BPF_RED_BLOCK) void k_sum_final(const double* __restrict__ partials, int n_partials,
                                                             FilterScalars* sc, int slot, int update_averages,
-                                                            int n_samples, double alpha_slow, double alpha_fast)
+                                                            int n_samples, double alpha_slow, double alpha_fast,
+                                                            unsigned long long* done_flag = nullptr,
+                                                            unsigned long long done_value = 0ull)
 {
   __shared__ double s_wave[4];
   double acc = 0.0;
@@ -117,6 +121,11 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_sum_final(const double* __res
         sc->v[1] = ws;
         sc->v[2] = wf;
       }
+    }
+    if (done_flag != nullptr)
+    {
+      __threadfence_system();
+      __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

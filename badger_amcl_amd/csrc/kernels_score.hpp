@@ -200,7 +200,13 @@ __device__ unsigned long long g_phase_cycles[kPhaseWaves][8];
 #define PHASE_MARK(idx)
 #endif
 
-template <bool COUNT_ONLY, bool TABLE_IN_LDS>
+// HOST_OUT: the host-buffer seam (abi_planar.inl) -- the new weights also go to a pinned array on the host (A.w_host,
+// dense 8-byte stores: 0.8 MB per 100 k particles leave over PCIe while the kernel is still working, no download
+// behind it).  k_seam_done, the launch behind it, folds the block partials and tells the host.  (A ticket per
+// block for "the last block tells the host" was tried: 1 000 same-address atomics at the end of a one-round kernel
+// serialise -- a 50 k-particle launch took 75 us instead of 40 -- and a system-scope release per block costs an L2
+// write-back each.)
+template <bool COUNT_ONLY, bool TABLE_IN_LDS, bool HOST_OUT = false>
 __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const FieldScoreArgs A)
 {
 #ifdef BPF_PHASE_TIMING
@@ -412,6 +418,8 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
       double w = A.p.w[i] * p;
       w *= recalc_factor(M, A.p.x[i], A.p.y[i], A.off_map_factor, A.non_free_factor, A.non_free_radius);
       A.p.w[i] = w;
+      if (HOST_OUT)  // plain stores: 16 neighbouring weights leave as one 128-byte write (a system-scope atomic store
+        A.w_host[i] = w;  // per lane is its own PCIe packet: 50 k of them backed up for 25 us behind the launch)
       wsum += w;
     }
     PHASE_MARK(4);  // epilogue
@@ -429,7 +437,9 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
       s_part[wave] = ws;
     __syncthreads();
     if (tid == 0)
+    {
       A.block_partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    }
   }
   PHASE_MARK(5);  // block partial
 #ifdef BPF_PHASE_TIMING
@@ -445,6 +455,29 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
     }
   }
 #endif
+}
+
+// Behind a HOST_OUT scoring launch: the launch's weight total (its block partials folded in block order, fixed shape)
+// and the word the host polls, both into pinned host memory.  A launch boundary orders them behind the weights.
+__global__ __launch_bounds__(256) void k_seam_done(const double* __restrict__ partials, int n_partials,
+                                                  double* total_host, unsigned long long* done_flag,
+                                                  unsigned long long done_value)
+{
+  __shared__ double s_wave[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += 256)
+    acc += partials[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0)
+    s_wave[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    __hip_atomic_store(total_host, (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(done_flag, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---------------------------------------------------------------------------------------

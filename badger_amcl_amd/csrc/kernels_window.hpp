@@ -93,6 +93,29 @@ __global__ __launch_bounds__(256) void k_field_prep(ParticlesDev p, int n, MapDe
         (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
 
+// Seam A with host buffers (PlanarScanner::applyModelToSampleSet on the caller's std::vector<PFSample>): a chunk of the
+// 32-byte AoS records as the copy engine left them -> the SoA set AND the per-particle (Qx, Qy, cos, sin) in one pass,
+// so a chunk costs one small launch in front of its scoring launch instead of two.  The scan's staging block rides
+// along exactly as in k_field_prep.
+__global__ __launch_bounds__(256) void k_field_prep_aos(const double4* __restrict__ aos, ParticlesDev p, int n, MapDev M,
+                                                       double ax, double ay, double ath, double4* __restrict__ prep,
+                                                       const uint4* __restrict__ stage_src,
+                                                       uint4* __restrict__ stage_dst, int stage_n16)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (stage_src != nullptr && i < stage_n16)
+    stage_dst[i] = stage_src[i];
+  if (i >= n)
+    return;
+  const double4 v = aos[i];
+  p.x[i] = v.x;
+  p.y[i] = v.y;
+  p.th[i] = v.z;
+  p.w[i] = v.w;
+  bool valid;
+  prep[i] = field_prep_of(M, v.x, v.y, v.z, ax, ay, ath, &valid);
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_field_windows(const double* __restrict__ stats, int n_stat_blocks,
                                                        const double2* __restrict__ beams, int n_beams, MapDev M,

@@ -29,6 +29,8 @@ OPT_STATS_HOST = 7
 OPT_LUT_HOST = 8
 OPT_KLD_PERSISTENT = 9
 OPT_LUT_EXACT_EDT = 10
+OPT_HOST_AUTO_REGISTER = 11
+OPT_SEAM_CHUNKS = 12
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 
@@ -91,6 +93,23 @@ class Engine:
         self.check(self.lib.bpf_profile_get(self.h, C.byref(p)))
         names = ["score", "reduce", "normalize", "cdf", "draw", "finalize", "score_window", "score_aux", "motion"]
         return {n: {"ms": p.ms[i], "launches": p.launches[i]} for i, n in enumerate(names)}
+
+    def registerHostBuffer(self, array):
+        """Pins a caller-owned numpy buffer for the host-buffer entry points (bpf_host_buffer_register): the owner
+        keeps it allocated until unregisterHostBuffer / close."""
+        self.check(self.lib.bpf_host_buffer_register(self.h, C.c_void_p(array.ctypes.data), array.nbytes))
+
+    def unregisterHostBuffer(self, array):
+        self.check(self.lib.bpf_host_buffer_unregister(self.h, C.c_void_p(array.ctypes.data)))
+
+    def isHostBufferRegistered(self, array):
+        return bool(self.lib.bpf_host_buffer_is_registered(self.h, C.c_void_p(array.ctypes.data), array.nbytes))
+
+    def seam_last_plan(self):
+        """(chunks, pinned) of the last applyModelToSampleSet: 0 chunks = the plain upload / score / download."""
+        a, b = C.c_int(), C.c_int()
+        self.check(self.lib.bpf_seam_last_plan(self.h, C.byref(a), C.byref(b)))
+        return a.value, bool(b.value)
 
     def set_option(self, option, value):
         self.check(self.lib.bpf_set_option(self.h, option, int(value)))
@@ -309,12 +328,17 @@ class ParticleFilter:
         self.e.check(self.e.lib.bpf_pf_get_state(self.e.h, C.byref(st)))
         return st
 
-    def getCurrentSet(self):
+    def getCurrentSet(self, out=None):
+        """The current set copied to the host; `out` = the caller's own [max_samples, 4] buffer (e.g. the registered
+        `samples` storage of a host-side set): the result is then a view of it, not a copy."""
         st = self.getState()
-        out = np.zeros((self.max_samples, 4), dtype=np.float64)
+        mine = out is None
+        if mine:
+            out = np.empty((self.max_samples, 4), dtype=np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape[0] >= st.sample_count
         n = C.c_int()
-        self.e.check(self.e.lib.bpf_pf_get_samples(self.e.h, _dp(out), self.max_samples, C.byref(n)))
-        return PFSampleSet(out[:n.value].copy(), st)
+        self.e.check(self.e.lib.bpf_pf_get_samples(self.e.h, _dp(out), out.shape[0], C.byref(n)))
+        return PFSampleSet(out[:n.value].copy() if mine else out[:n.value], st)
 
     def isConverged(self):
         return bool(self.getState().converged)

@@ -56,6 +56,26 @@ struct PFSample
   std::array<double, 3> pose;  // x, y, theta
   double weight;
 };
+
+// Pins a sample buffer the caller owns for as long as this object lives (bpf_host_buffer_register /
+// _unregister): what a ParticleFilter that keeps its `samples` vector in host memory (allocated once at max_samples,
+// particle_filter.cpp:62-89) holds beside the vector, so that applyModelToSampleSet / initWithSamples / getCurrentSet
+// move it at PCIe rate.  The vector must not be resized while it is pinned.
+class PinnedSamples
+{
+public:
+  PinnedSamples(std::shared_ptr<Engine> e, std::vector<PFSample>& samples) : e_(std::move(e)), ptr_(samples.data())
+  {
+    e_->check(bpf_host_buffer_register(e_->get(), ptr_, samples.size() * sizeof(PFSample)));
+  }
+  ~PinnedSamples() { (void)bpf_host_buffer_unregister(e_->get(), ptr_); }
+  PinnedSamples(const PinnedSamples&) = delete;
+  PinnedSamples& operator=(const PinnedSamples&) = delete;
+
+private:
+  std::shared_ptr<Engine> e_;
+  void* ptr_;
+};
 static_assert(sizeof(PFSample) == 32, "PFSample must match the reference's 32-byte AoS record");
 
 struct PFSampleSet

@@ -106,6 +106,21 @@ int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, cons
  * reference-named calls. */
 int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist);
 
+/* ------------------------------------------------------------------ caller-owned host buffers
+ * The reference keeps its particles in host memory: ParticleFilter allocates `samples` once at max_samples
+ * (src/amcl/pf/particle_filter.cpp:62-89, include/amcl/pf/particle_filter.h:70-75) and every sensor model gets that
+ * vector (planar_scanner.cpp:141-164).  Registering the buffer (hipHostRegister: pins it and maps it for the copy
+ * engines, ~1 ms, once) lets the host-buffer entry points below move it at PCIe rate without a staging copy by the
+ * calling thread.  [ptr, ptr + bytes) need not be aligned.  The owner must keep the memory allocated until
+ * bpf_host_buffer_unregister (same ptr) or bpf_destroy.  Unregistered buffers work everywhere, through the runtime's
+ * bounce buffers.  bpf_host_buffer_is_registered: 1 when the whole range lies inside one registered buffer. */
+int bpf_host_buffer_register(bpf_engine* e, void* ptr, size_t bytes);
+int bpf_host_buffer_unregister(bpf_engine* e, void* ptr);
+int bpf_host_buffer_is_registered(bpf_engine* e, const void* ptr, size_t bytes);
+/* what the last bpf_planar_apply_model_to_sample_set did: chunks of the pipelined form (0 = the plain upload / score /
+ * download sequence); pinned = the buffer lies in a registered range */
+int bpf_seam_last_plan(bpf_engine* e, int* chunks_out, int* pinned_out);
+
 /* ------------------------------------------------------------------ planar scanner
  * PlanarScanner::{init, setModel*, setMapFactors, setPlanarScannerPose}
  * (include/amcl/sensors/planar_scanner.h:62-93, planar_scanner.cpp:49-121,535-538). */
@@ -130,7 +145,12 @@ int bpf_planar_set_scanner_pose(bpf_engine* e, const double pose[3]);
  * Multiplies samples[i].weight in place for i < sample_count and returns their sum
  * (0.0 on failure, like the reference); *status (nullable) receives a BPF_* code.
  * ranges/angles/range_count/range_max are PlanarData (planar_scanner.h:45-54);
- * set_converged is PFSampleSet::converged (only the prob model reads it). */
+ * set_converged is PFSampleSet::converged (only the prob model reads it).
+ * Sets of 40 k particles or more under a likelihood-field model go through in chunks (BPF_OPT_SEAM_CHUNKS): chunk k
+ * is scored while chunk k + 1 crosses PCIe, the scoring launches store the weights into pinned host memory themselves
+ * (no download) and the calling thread writes chunk k's weights into the records while chunk k + 1 is scored.  A
+ * registered buffer (bpf_host_buffer_register) is read by the copy engine without a staging copy by the caller.
+ * Same weights bit for bit as the one-launch form. */
 double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int sample_count, int set_converged,
                                             const double* ranges, const double* angles, int range_count,
                                             double range_max, int* status);
@@ -212,6 +232,15 @@ enum
                                * map_->updateDistancesLUT there, planar_scanner.cpp:74,91,112) is the reference's
                                * brushfire on the host; 1 = the exact EDT on the device (milliseconds, values differ from
                                * the reference's in < 1 % of the cells) */
+  BPF_OPT_HOST_AUTO_REGISTER = 11, /* default 0.  1 = the CALLER'S PROMISE that every host buffer of 64 KB or more it hands to
+                               * bpf_planar_apply_model_to_sample_set / bpf_pf_set_samples / bpf_pf_get_samples stays
+                               * allocated until bpf_destroy: the engine then pins each one on first sight
+                               * (hipHostRegister, ~1 ms once) and keeps the registration, keyed by address range.  A
+                               * buffer freed or re-allocated under a kept registration makes the next copy fault --
+                               * hence off by default; bpf_host_buffer_register is the per-buffer, owner-controlled form */
+  BPF_OPT_SEAM_CHUNKS = 12,   /* default 0 = by size (20 k particles or more per chunk, at most 4): chunks of the pipelined
+                               * host-buffer seam (bpf_planar_apply_model_to_sample_set); 1 = the plain upload / score /
+                               * download sequence.  Same weights either way. */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.
