@@ -915,6 +915,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->seam_chunks = value < 0 ? 0 : (value > kSeamMaxChunks ? kSeamMaxChunks : value);
   else if (option == BPF_OPT_KLD_PERSISTENT)
     e->kld_persistent = value != 0;
+  else if (option == BPF_OPT_KLD_LOCAL)
+    e->kld_local = value != 0;
   else if (option == BPF_OPT_STATS_HOST)
   {
     e->stats_host = value != 0;

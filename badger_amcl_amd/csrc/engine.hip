@@ -22,6 +22,7 @@
 #include "kernels_lut3d.hpp"
 #include "kernels_motion.hpp"
 #include "kernels_kld.hpp"
+#include "kernels_kld2.hpp"
 #include "kernels_recovery.hpp"
 #include "kernels_pf.hpp"
 #include "kernels_fused.hpp"

@@ -345,6 +345,12 @@ struct bpf_engine
   DevBuf<unsigned long long> d_kld_hkey;
   DevBuf<int> d_kld_htmin, d_kld_slot, d_kld_cur, d_kld_first, d_kld_child, d_kld_flags, d_kld_limit;
   DevBuf<int2> d_kld_delta, d_kld_tiles, d_kld_counts;
+  // the tree in LDS-sized pieces (kernels_kld2.hpp)
+  DevBuf<int> d_kld2_int;       // tkeys[n] bucket[n] bk[n] cnt[N] off[N + 1] fill[N] n_tkeys n_top status[2]
+  DevBuf<Kld2Top> d_kld2_top;
+  bool kld_local = true;        // BPF_OPT_KLD_LOCAL
+  bool kld2_attr_set = false;
+  int kld_last_form = 0;        // diagnostics: 2 = LDS pieces, 1 = level loop, 3 = persistent
   PinnedBuf<int> h_kld;
   std::vector<int> kld_limit_host;
   double kld_limit_key[4] = { -1, -1, -1, -1 };  // pop_err, pop_z, min_samples, max_samples of the cached table

@@ -408,7 +408,7 @@ int resample_block(bpf_engine* e, int window, bool systematic, const double* tar
 // *handled = false when a key does not fit the 64-bit packing or the tree is deeper than the level budget
 // (the caller then replays on the host as before).
 int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, int* leaf_out, int* bins_out,
-                       bool whole_stream = false)
+                       bool whole_stream = false, bool allow_local = true)
 {
   *handled = false;
   const int n = maxs;
@@ -453,6 +453,7 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   hipLaunchKernelGGL(k_kld_hash, grid, block, 0, e->stream, K);
   if (e->kld_persistent)
   {
+    e->kld_last_form = 3;
     // the whole stream in one resident round of 1024-thread blocks: the level loop, the prefix sums and the stop test
     // run in ONE launch with grid barriers between the levels (k_kld_tree_persistent)
     const int pgrid = blocks_for(n, kKldBlock);
@@ -519,6 +520,95 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
       e->kld_persistent = false;
       return kld_tree_on_device(e, maxs, handled, stop_out, leaf_out, bins_out, whole_stream);
     }
+  }
+  const bool local = e->kld_local && allow_local;
+  e->kld_last_form = local ? 2 : 1;
+  if (local)
+  {
+    // the tree in LDS-sized pieces (kernels_kld2.hpp): no level loop, no host round trip until the result
+    const size_t nn = (size_t)n;
+    const int n_tiles = blocks_for(n, 256);
+    HIPCHK(e, e->d_kld2_int.reserve(5 * nn + 3 * (size_t)kKld2Nodes + 8 + (size_t)n_tiles));
+    HIPCHK(e, e->d_kld2_top.reserve((size_t)kKld2Nodes));
+    if (!e->kld2_attr_set)
+    {
+      HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kld2_top),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kKld2LdsBytes));
+      HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kld2_subtrees),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kKld2LdsBytes));
+      e->kld2_attr_set = true;
+    }
+    Kld2Args L{};
+    L.K = K;
+    L.pk = reinterpret_cast<unsigned long long*>(e->d_kld2_int.p);  // first: 8-byte aligned
+    int* base = e->d_kld2_int.p + 2 * nn;
+    L.tkeys = base;
+    L.bucket = base + nn;
+    L.bk = base + 2 * nn;
+    L.cnt = base + 3 * nn;
+    L.off = L.cnt + kKld2Nodes;
+    L.fill = L.off + kKld2Nodes + 1;
+    L.n_tkeys = L.fill + kKld2Nodes;
+    L.n_top = L.n_tkeys + 1;
+    L.status = L.n_top + 1;
+    int* tile_first = L.status + 4;
+    L.tile_first = tile_first;
+    L.n_tiles = n_tiles;
+    L.top = e->d_kld2_top.p;
+    L.counts = e->d_kld_counts.p;
+    L.whole_stream = whole_stream ? 1 : 0;
+    e->kld_generation = (e->kld_generation % 0x3fffffff) + 1;
+    L.generation = e->kld_generation;
+    volatile int* res = e->h_kld.p + 16;
+    res[0] = 0;
+    L.result_host = res;
+    hipLaunchKernelGGL(k_kld2_init, dim3(n_tiles), dim3(256), 0, e->stream, K, tile_first);
+    hipLaunchKernelGGL(k_kld2_compact, dim3(n_tiles), dim3(256), 0, e->stream, L);
+    hipLaunchKernelGGL(k_kld2_top, dim3(1), dim3(kKld2Block), kKld2LdsBytes, e->stream, L);
+    hipLaunchKernelGGL(k_kld2_route, dim3(blocks_for(n, kKld2Block)), dim3(kKld2Block), 0, e->stream, L);
+    hipLaunchKernelGGL(k_kld2_offsets, dim3(1), dim3(1024), 0, e->stream, L);
+    hipLaunchKernelGGL(k_kld2_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, L);
+    hipLaunchKernelGGL(k_kld2_subtrees, dim3(blocks_for(n, kKld2Span) + 1), dim3(kKld2Block), kKld2LdsBytes, e->stream,
+                       L);
+    hipLaunchKernelGGL(k_kld_scan_tiles, dim3(tiles), dim3(256), 0, e->stream, (const int2*)e->d_kld_delta.p, n,
+                       e->d_kld_tiles.p);
+    hipLaunchKernelGGL(k_kld_scan_offsets, dim3(1), dim3(1024), 0, e->stream, e->d_kld_tiles.p, tiles);
+    hipLaunchKernelGGL(k_kld_scan_final, dim3(tiles), dim3(256), 0, e->stream, K, (const int2*)e->d_kld_tiles.p,
+                       e->d_kld_counts.p);
+    hipLaunchKernelGGL(k_kld2_result, dim3(1), dim3(64), 0, e->stream, L);
+    HIPCHK(e, hipGetLastError());
+    // the result block in pinned memory, its generation word last: one poll instead of three copies with a
+    // stream synchronisation each
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      bool seen = false;
+      for (unsigned spins = 0; !seen; ++spins)
+      {
+        seen = __atomic_load_n(e->h_kld.p + 16, __ATOMIC_ACQUIRE) == L.generation;
+        if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100))
+          break;
+        if (!seen)
+          __builtin_ia32_pause();
+      }
+      if (!seen)
+      {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (__atomic_load_n(e->h_kld.p + 16, __ATOMIC_ACQUIRE) != L.generation)
+          return e->fail(BPF_ERR_HIP, "k_kld2_result did not publish its result");
+      }
+    }
+    if (getenv("BPF_DEBUG"))
+      fprintf(stderr, "[kld pieces] n %d tree keys %d status %d largest bucket %d stop %d leaf %d bins %d\n", n, res[6],
+              res[5], res[7], res[2], res[3], res[4]);
+    if (res[1] != 0)
+      return BPF_OK;  // a key outside the packing range: not handled
+    if (res[5] != BPF_KLD2_OK)  // a bucket that does not fit a block, or a piece deeper than its budget
+      return kld_tree_on_device(e, maxs, handled, stop_out, leaf_out, bins_out, whole_stream, false);
+    *stop_out = res[2];
+    *leaf_out = res[3];
+    *bins_out = res[4];
+    *handled = true;
+    return BPF_OK;
   }
   hipLaunchKernelGGL(k_kld_init, grid, block, 0, e->stream, K);
   hipLaunchKernelGGL(k_kld_root_first, dim3(1), dim3(1024), 0, e->stream, K);

@@ -31,6 +31,7 @@ OPT_KLD_PERSISTENT = 9
 OPT_LUT_EXACT_EDT = 10
 OPT_HOST_AUTO_REGISTER = 11
 OPT_SEAM_CHUNKS = 12
+OPT_KLD_LOCAL = 13
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 
@@ -104,6 +105,12 @@ class Engine:
 
     def isHostBufferRegistered(self, array):
         return bool(self.lib.bpf_host_buffer_is_registered(self.h, C.c_void_p(array.ctypes.data), array.nbytes))
+
+    def kld_last_form(self):
+        """2 = the last device-side histogram tree was grown in LDS-sized pieces, 1 = level loop, 3 = persistent."""
+        a = C.c_int()
+        self.check(self.lib.bpf_kld_last_form(self.h, C.byref(a)))
+        return a.value
 
     def seam_last_plan(self):
         """(chunks, pinned) of the last applyModelToSampleSet: 0 chunks = the plain upload / score / download."""

@@ -117,6 +117,9 @@ int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist);
 int bpf_host_buffer_register(bpf_engine* e, void* ptr, size_t bytes);
 int bpf_host_buffer_unregister(bpf_engine* e, void* ptr);
 int bpf_host_buffer_is_registered(bpf_engine* e, const void* ptr, size_t bytes);
+/* which form the last device-side histogram tree took: 2 = grown in LDS-sized pieces (kernels_kld2.hpp), 1 = one launch
+ * pair per level (also after the pieces declined a stream), 3 = the persistent launch, 0 = none yet */
+int bpf_kld_last_form(bpf_engine* e, int* form_out);
 /* what the last bpf_planar_apply_model_to_sample_set did: chunks of the pipelined form (0 = the plain upload / score /
  * download sequence); pinned = the buffer lies in a registered range */
 int bpf_seam_last_plan(bpf_engine* e, int* chunks_out, int* pinned_out);
@@ -241,6 +244,10 @@ enum
   BPF_OPT_SEAM_CHUNKS = 12,   /* default 0 = by size (20 k particles or more per chunk, at most 4): chunks of the pipelined
                                * host-buffer seam (bpf_planar_apply_model_to_sample_set); 1 = the plain upload / score /
                                * download sequence.  Same weights either way. */
+  BPF_OPT_KLD_LOCAL = 13,     /* default 1: the device-side histogram tree of a long draw stream is grown in LDS-sized pieces
+                               * (one block grows the top from the first 2 048 keys, the later keys are routed through it
+                               * and blocks grow the subtrees below its nodes: kernels_kld2.hpp) instead of one launch
+                               * pair per level; 0 = the level loop.  Same tree. */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.

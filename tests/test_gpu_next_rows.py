@@ -351,3 +351,56 @@ def test_cluster_stats_small_sets_one_block_and_beyond_its_limits(engine, orc):
     pf2 = __import__("badger_amcl_amd").ParticleFilter(engine, 1, 10, 0.0, 0.0, 85.0)
     pf2.initWithSamples(one)
     _assert_stats_equal(pf2, _oracle_stats(orc, one, 10), exact=False)
+
+
+def _tree_counts(engine, orc, samples):
+    import badger_amcl_amd as bpf
+    n = samples.shape[0]
+    pf = bpf.ParticleFilter(engine, 100, n, 0.0, 0.0, 85.0)
+    pf.initWithSamples(samples)
+    st = pf.getState()
+    return st.leaf_count, st.bin_count, engine.kld_last_form()
+
+
+@pytest.mark.parametrize("kind", ["spread", "half", "line_then_blob", "small"])
+def test_histogram_tree_in_lds_pieces_equals_the_level_loop_and_the_oracle(engine, orc, kind):
+    """The device-side histogram tree of a long key stream (the set's PFKDTree, pf_kdtree.cpp:49-150) grown in
+    LDS-sized pieces (kernels_kld2.hpp) against the level-per-launch form and the oracle's tree: same leaf and bin
+    counts.  `line_then_blob` puts every later key below ONE node of the top tree (a bucket no block can hold): the
+    pieces decline and the level loop takes over."""
+    import badger_amcl_amd as bpf
+    rng = np.random.default_rng(11)
+    n = 60000
+    s = np.zeros((n, 4))
+    s[:, 3] = 1.0 / n
+    if kind == "spread":
+        s[:, 0] = rng.uniform(0, 100, n); s[:, 1] = rng.uniform(0, 100, n); s[:, 2] = rng.uniform(-3.1, 3.1, n)
+    elif kind == "half":
+        h = n // 2
+        s[:h, 0] = rng.normal(50, 0.2, h); s[:h, 1] = rng.normal(50, 0.2, h); s[:h, 2] = rng.normal(0.3, 0.05, h)
+        s[h:, 0] = rng.uniform(0, 100, n - h); s[h:, 1] = rng.uniform(0, 100, n - h)
+        s[h:, 2] = rng.uniform(-3.1, 3.1, n - h)
+        s[:] = s[rng.permutation(n)]
+    elif kind == "line_then_blob":
+        k = 2300  # more distinct bins than the top tree holds, all on a line far from the rest
+        s[:k, 0] = -500.0 - 0.5 * np.arange(k); s[:k, 1] = -500.0; s[:k, 2] = 0.0
+        s[k:, 0] = rng.uniform(0, 100, n - k); s[k:, 1] = rng.uniform(0, 100, n - k)
+        s[k:, 2] = rng.uniform(-3.1, 3.1, n - k)
+    else:
+        n = 9000  # fewer tree keys than one block's table: the top tree is the whole tree
+        s = s[:n]
+        s[:, 0] = rng.uniform(0, 20, n); s[:, 1] = rng.uniform(0, 20, n); s[:, 2] = rng.uniform(-1, 1, n)
+        s[:, 3] = 1.0 / n
+    otree = orc.ParticleFilter(100, s.shape[0], 0.0, 0.0, 85.0, seed=1)
+    otree.set_samples(s)
+    want_leaf = otree.leaf_count
+    got = {}
+    for local in (1, 0):
+        engine.set_option(bpf.pf.OPT_KLD_LOCAL, local)
+        try:
+            got[local] = _tree_counts(engine, orc, s)
+        finally:
+            engine.set_option(bpf.pf.OPT_KLD_LOCAL, 1)
+    assert got[1][:2] == got[0][:2] and got[1][0] == want_leaf
+    assert got[0][2] == 1
+    assert got[1][2] == (1 if kind == "line_then_blob" else 2)
