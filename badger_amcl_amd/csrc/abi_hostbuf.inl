@@ -41,7 +41,13 @@ int host_reg_add(bpf_engine* e, void* ptr, size_t bytes, bool automatic)
     (void)hipGetLastError();
     return e->fail(BPF_ERR_HIP, "hipHostRegister refused the buffer");
   }
-  e->host_regs.push_back(bpf_engine::HostReg{ a, bytes, automatic });
+  void* dv = nullptr;
+  if (hipHostGetDevicePointer(&dv, ptr, 0) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    dv = nullptr;
+  }
+  e->host_regs.push_back(bpf_engine::HostReg{ a, bytes, automatic, reinterpret_cast<uintptr_t>(dv) });
   return BPF_OK;
 }
 

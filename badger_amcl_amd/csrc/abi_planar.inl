@@ -188,13 +188,9 @@ int apply_model_pipelined(bpf_engine* e, double* samples, int n, int set_converg
   // the smaller one then (40 %): the second chunk's copy (which runs beside it from the start) is there when it ends.
   const double4* dev_view = nullptr;
   if (pinned)
-  {
-    void* dv = nullptr;
-    if (hipHostGetDevicePointer(&dv, samples, 0) == hipSuccess && dv != nullptr)
-      dev_view = static_cast<const double4*>(dv);
-    else
-      (void)hipGetLastError();
-  }
+    if (const bpf_engine::HostReg* r = host_reg_find(e, samples, (size_t)n * sizeof(double4)))
+      if (r->dev_base != 0)
+        dev_view = reinterpret_cast<const double4*>(r->dev_base + (reinterpret_cast<uintptr_t>(samples) - r->base));
   const bool first_direct = dev_view != nullptr && chunks == 2 && e->seam_chunks == 0;
   auto lo_of = [&](int c) {
     const long long num = first_direct && c == 1 ? (long long)n * 2 / 5 : (long long)n * c / chunks;

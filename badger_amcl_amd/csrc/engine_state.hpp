@@ -395,6 +395,7 @@ struct bpf_engine
     uintptr_t base;
     size_t bytes;
     bool automatic;  // made by BPF_OPT_HOST_AUTO_REGISTER, not by bpf_host_buffer_register
+    uintptr_t dev_base;  // the range as a kernel addresses it (hipHostGetDevicePointer of base), 0: none
   };
   std::vector<HostReg> host_regs;
   bool host_auto_register = false;  // BPF_OPT_HOST_AUTO_REGISTER

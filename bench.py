@@ -793,6 +793,8 @@ def parse_args(argv=None):
                     help="other_configs / strong_scaling / exchange_ms sub-records in the same line (auto: when the run "
                          "is the plain headline)")
     ap.add_argument("--sub-cpu-budget", type=float, default=4.0, help="seconds of CPU baseline work per sub-record")
+    ap.add_argument("--host-path", default="on", choices=["on", "off"],
+                    help="also time Seam A with host buffers (host_buffer_path; N = 1 only)")
     args = ap.parse_args(argv)
     args.strong_total = None
     return args
@@ -859,7 +861,8 @@ def main():
     gc.freeze()  # see measure()
 
     line = measure(args, ctx, args.steps, args.warmup, args.prewarm, args.cpu_budget, all_cores=(world == 1),
-                   host_path=(world == 1), compare_exchanges=(extras and ctx.dist is not None),
+                   host_path=(world == 1 and args.host_path == "on"),
+                   compare_exchanges=(extras and ctx.dist is not None),
                    prewarm_s=args.prewarm_seconds)
     if extras:
         sub_budget = min(args.sub_cpu_budget, args.cpu_budget)

@@ -14,7 +14,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p -- python3 bench.py --steps 5 --warmup 2 --cpu-budget 0 $ARGS > $OUT/p$i.out 2>&1 || echo "pass $i failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p -- python3 bench.py --steps 5 --warmup 2 --prewarm 3 --prewarm-seconds 0 --cpu-budget 0 --extras off --host-path off $ARGS > $OUT/p$i.out 2>&1 || echo "pass $i failed"
 done
 python3 - "$OUT" "$TAG" "$KEY" $ARGS <<'PY'
 import csv, collections, glob, json, os, sys
@@ -41,7 +41,7 @@ for line in open(sys.argv[1] + "/p1.out", errors="replace"):
         d = json.loads(line)
         n = d["config"]["particles_per_gpu"]
         w = d["config"]["workload"]
-        b = 65536 if "point cloud" in w or "1024" in w else (181 if "181" in w else 1081)
+        b = 65536 if "point cloud" in w or "1024-point" in w else (181 if "181" in w else 1081)
 print(n, b)
 PY
 )
