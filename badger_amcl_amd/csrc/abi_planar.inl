@@ -127,6 +127,64 @@ bool seam_wait_word(const unsigned long long* word, unsigned long long value)
   }
 }
 
+// Seam A on a REGISTERED host buffer, one scoring launch and no copy in either direction (HOST_MODE 2 of
+// k_score_field): the waves read the caller's records over PCIe as they reach them and write them back whole with the
+// new weight; k_seam_done folds the total and publishes the word this thread polls.  Nothing is left for the host to
+// do but wait.  Same per-particle arithmetic as the resident form (field_prep_of, same beams and table): the same
+// weights bit for bit; the total is the fixed-shape sum of the launch's block partials.
+int apply_model_records(bpf_engine* e, double* samples, int n, int set_converged, const double* ranges,
+                        const double* angles, int rc, double range_max, bool* done)
+{
+  *done = false;
+  const PlanarModel& pm = e->pm;
+  if (e->seam_chunks != 0 || !e->have_map || !e->have_lut || !pm.configured || rc <= 0 || !ranges || !angles || n < 4096)
+    return BPF_OK;
+  if (pm.model == BPF_MODEL_BEAM || (pm.model == BPF_MODEL_LIKELIHOOD_FIELD_PROB && pm.do_beamskip && set_converged))
+    return BPF_OK;
+  if (e->map.n_levels + 1 > kTableLdsMax)
+    return BPF_OK;
+  if (!host_buffer_pinned(e, samples, (size_t)n * sizeof(double4)))
+    return BPF_OK;
+  const bpf_engine::HostReg* r = host_reg_find(e, samples, (size_t)n * sizeof(double4));
+  if (r == nullptr || r->dev_base == 0 || (reinterpret_cast<uintptr_t>(samples) & 15) != 0)
+    return BPF_OK;  // (the records are read and written as 16-byte pairs)
+  double4* rec = reinterpret_cast<double4*>(r->dev_base + (reinterpret_cast<uintptr_t>(samples) - r->base));
+  int rcode = seam_resources(e);
+  if (rcode != BPF_OK)
+    return rcode;
+  static const bool dbg = getenv("BPF_DEBUG_SEAM") != nullptr;
+  auto now = []() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  const double t0 = dbg ? now() : 0.0;
+  e->fused_partials = 0;
+  e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
+  ScanSlot* s = nullptr;
+  FieldScan fs;
+  rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s, &fs);
+  if (rcode != BPF_OK)
+    return rcode;
+  e->evals_last = (long long)n * fs.n_valid;
+  const unsigned long long gen = ++e->seam_generation;
+  const FieldHostOut out{ rec, nullptr, e->h_seam_totals.p, e->d_seam_partials.p, e->h_seam_flags.p, gen };
+  rcode = launch_field(e, ParticlesDev{ nullptr, nullptr, nullptr, nullptr }, n, s, fs, nullptr, 0, false, nullptr, &out);
+  if (rcode != BPF_OK)
+    return rcode;
+  rcode = release_slot(e, s);
+  if (rcode != BPF_OK)
+    return rcode;
+  const double t1 = dbg ? now() : 0.0;
+  if (!seam_wait_word(e->h_seam_flags.p, gen))
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->h_scalars.p->v[0] = *const_cast<const volatile double*>(e->h_seam_totals.p);
+  if (dbg)
+    fprintf(stderr, "seam: records in place, one launch: stage + issue %.1f us, waiting %.1f us\n", t1 - t0, now() - t1);
+  e->last_seam_chunks = -1;
+  e->last_seam_registered = true;
+  *done = true;
+  return BPF_OK;
+}
+
 // Seam A with the particles in HOST memory, pipelined.  What the plain sequence spends at 100 k x 1081 (measured,
 // tools/ubench/pcie_probe.hip): 64 us for the 3.2 MB upload (the link's rate, pinned or not), 5 + 77 us for the
 // launches, ~10 us for the total, 22-44 us for the download of the weights, ~30 us for this thread to write them into
@@ -222,7 +280,7 @@ int apply_model_pipelined(bpf_engine* e, double* samples, int n, int set_converg
     p.x += lo; p.y += lo; p.th += lo; p.w += lo;
     FieldScan fc = fs;
     fc.copy_pending = fs.copy_pending && c == 0;  // the staging block rides with the first chunk's prep launch
-    const FieldHostOut out{ hw + lo, e->h_seam_totals.p + c, e->d_seam_partials.p + (size_t)c * kSeamMaxBlocks,
+    const FieldHostOut out{ nullptr, hw + lo, e->h_seam_totals.p + c, e->d_seam_partials.p + (size_t)c * kSeamMaxBlocks,
                             e->h_seam_flags.p + c, gen };
     rcode = launch_field(e, p, cnt, s, fc, nullptr, 0, false, direct ? dev_view + lo : e->d_aos.p + lo, &out);
     if (rcode != BPF_OK)
@@ -291,6 +349,11 @@ double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int 
     return bail(rc);
   e->last_seam_chunks = 0;
   bool piped = false;
+  rc = apply_model_records(e, samples, sample_count, set_converged, ranges, angles, range_count, range_max, &piped);
+  if (rc != BPF_OK)
+    return bail(rc);
+  if (piped)
+    return e->h_scalars.p->v[0];
   rc = apply_model_pipelined(e, samples, sample_count, set_converged, ranges, angles, range_count, range_max, &piped);
   if (!piped)
     e->last_seam_registered = host_reg_find(e, samples, (size_t)sample_count * sizeof(double4)) != nullptr;

@@ -55,7 +55,8 @@ struct FieldScoreArgs
   ParticlesDev p;
   int n;
   const double4* prep;   // per particle (Qx, Qy, cos, sin) from k_field_prep
-  double* w_host;        // HOST_OUT kernels (the host-buffer seam): pinned host array that receives the new weights too
+  double* w_host;        // HOST_MODE 1 (the host-buffer seam): pinned host array that receives the new weights too
+  double4* rec;          // HOST_MODE 2: the caller's records in registered host memory, read and written in place
   const double2* beams;  // per valid beam: r*cos(bearing)/res, r*sin(bearing)/res
   int n_beams;
   const double* table;   // per LUT level (+1 off-map entry): the per-beam term

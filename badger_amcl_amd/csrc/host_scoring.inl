@@ -157,6 +157,7 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
 // host_out != nullptr: the HOST_OUT form of the scoring kernel (weights to a pinned array as well, a done word).
 struct FieldHostOut
 {
+  double4* rec;      // non-null: HOST_MODE 2 -- the caller's records in registered host memory, read and written in place
   double* w_host;
   double* total_host;
   double* partials;  // >= blocks of the launch
@@ -193,15 +194,31 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   const bool table_lds = !count_only && fs.table_len <= kTableLdsMax;
   const size_t table_bytes = table_lds ? (((size_t)fs.table_len * sizeof(double) + 15) & ~(size_t)15) : 0;
   // at least the four block partials that reuse the head of the block (kernels_score.hpp)
-  const size_t lds = std::max<size_t>(32, (size_t)fs.n_staged * sizeof(double2) + table_bytes);
+  // (+ the record stash of HOST_MODE 2: 4 waves x 16 records behind the beams)
+  const size_t lds = std::max<size_t>(32, (size_t)fs.n_staged * sizeof(double2) + table_bytes) +
+                     (host_out != nullptr && host_out->rec != nullptr ? (size_t)(2048 + 32) : 0);
   // per-particle scanner pose / trig once per update (shared by both scoring forms)
   const int prep_blocks = blocks_for(n, 256);
   HIPCHK(e, e->d_prep.reserve((size_t)n));
   HIPCHK(e, e->d_prep_stats.reserve((size_t)prep_blocks * kPrepStats));
+  const bool rec_mode = host_out != nullptr && host_out->rec != nullptr;
   if (host_out != nullptr)
   {
     A.w_host = host_out->w_host;
+    A.rec = host_out->rec;
   }
+  if (rec_mode)
+  {
+    // no prep launch to ride on: a small copy launch brings the scan's staging block over
+    if (fs.copy_pending)
+    {
+      const int n16 = (int)((fs.bytes + 15) / 16);
+      ProfScope pa(e, BPF_K_SCORE_AUX);
+      hipLaunchKernelGGL(k_copy16, dim3(blocks_for(n16, 256)), dim3(256), 0, e->stream,
+                         reinterpret_cast<const uint4*>(s->host.p), reinterpret_cast<uint4*>(s->dev.p), n16);
+    }
+  }
+  else
   {
     const int n16 = (int)((fs.bytes + 15) / 16);
     const bool ride = fs.copy_pending && n16 <= prep_blocks * 256;
@@ -226,7 +243,8 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   if (host_out != nullptr && (count_only || !table_lds))
     return e->fail(BPF_ERR_UNSUPPORTED, "host-out scoring kernel: table-in-LDS scoring form only");
   const void* kfn = count_only ? reinterpret_cast<const void*>(&k_score_field<true, false>)
-                               : (host_out != nullptr ? reinterpret_cast<const void*>(&k_score_field<false, true, true>)
+                               : (rec_mode ? reinterpret_cast<const void*>(&k_score_field<false, true, 2>)
+                                  : host_out != nullptr ? reinterpret_cast<const void*>(&k_score_field<false, true, 1>)
                                   : (table_lds ? reinterpret_cast<const void*>(&k_score_field<false, true>)
                                                : reinterpret_cast<const void*>(&k_score_field<false, false>)));
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api_blocks, kfn, 256, lds) != hipSuccess || api_blocks < 1)
@@ -243,6 +261,9 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
     // graded partition (see k_score_field): the share of a wave by the placement round of its block.  The shares
     // were measured on MI355X at 4 blocks per CU (tools/phase_timing.py): 40 / 28 / 19 / 13 % of a SIMD's particles
     // make every wave end within a few microseconds of the others (equal shares: 46 .. 86 us).
+    // (HOST_MODE 2, whose records arrive over PCIe in dispatch order while the kernel runs, was measured with steeper
+    // and with equal shares: 160 us with these, 169-177 with 46/28/16/10 ... 60/24/11/5, 173 with equal shares -- the
+    // launch is bound by the 6.4 MB it moves over PCIe, not by the skew of its waves)
     static const double kShare[4] = { 0.40, 0.28, 0.19, 0.13 };
     const double per_simd = (double)n / (e->n_cu * 4);
     int base = 0;
@@ -326,7 +347,10 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
     LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<true, false>), dim3(grid), dim3(256), lds, A);
   else if (host_out != nullptr)
   {
-    LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true, true>), dim3(grid), dim3(256), lds, A);
+    if (rec_mode)
+      LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true, 2>), dim3(grid), dim3(256), lds, A);
+    else
+      LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true, 1>), dim3(grid), dim3(256), lds, A);
     hipLaunchKernelGGL(k_seam_done, dim3(1), dim3(256), 0, e->stream, (const double*)host_out->partials, grid,
                        host_out->total_host, host_out->flag, host_out->value);
   }

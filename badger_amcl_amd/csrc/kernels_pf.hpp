@@ -197,6 +197,15 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_normalize_fused(double* __res
 }
 
 // one launch instead of four device-to-device copies
+// 16-byte words from pinned host memory to the device: the scan's staging block in front of a scoring launch that has
+// no prep launch to carry it (HOST_MODE 2 of k_score_field)
+__global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16)
+    dst[i] = src[i];
+}
+
 __global__ void k_copy4(ParticlesDev dst, ParticlesDev src, int n)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

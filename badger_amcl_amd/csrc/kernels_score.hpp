@@ -206,9 +206,20 @@ __device__ unsigned long long g_phase_cycles[kPhaseWaves][8];
 // block for "the last block tells the host" was tried: 1 000 same-address atomics at the end of a one-round kernel
 // serialise -- a 50 k-particle launch took 75 us instead of 40 -- and a system-scope release per block costs an L2
 // write-back each.)
-template <bool COUNT_ONLY, bool TABLE_IN_LDS, bool HOST_OUT = false>
+//
+// HOST_MODE 2 (a REGISTERED buffer): no copy at all -- every wave reads the caller's 32-byte records from host memory
+// itself when it reaches them (A.rec, zero-copy over PCIe), forms (Qx, Qy, cos, sin) with the prep launch's own
+// function, and writes the records back WHOLE with the new weight (16 neighbouring records = 512 contiguous bytes per
+// trip: full-line posted writes that leave while the kernel works; an 8-byte store per record at the records' stride
+// is one PCIe packet each and takes 105 us per 100 k).  The transfer and the scoring overlap as far as one resident
+// round of static shares lets them (a wave whose records arrive late still has its whole share to do): 160 us for
+// 100 k x 1081 -- 127 us when only the weights are stored (to a pinned array), the whole records' way back costs the
+// rest, and saves the calling thread the 40 us it takes to write 100 k weights into the records itself.
+template <bool COUNT_ONLY, bool TABLE_IN_LDS, int HOST_MODE = 0>
 __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const FieldScoreArgs A)
 {
+  constexpr bool HOST_OUT = HOST_MODE == 1;
+  constexpr bool HOST_REC = HOST_MODE == 2;
 #ifdef BPF_PHASE_TIMING
   unsigned long long _ph[6] = { 0, 0, 0, 0, 0, 0 };
   long long _t = clock64();
@@ -220,6 +231,10 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
   const int table_lds_len = (TABLE_IN_LDS && !COUNT_ONLY) ? A.table_len : 0;
   double* s_table = reinterpret_cast<double*>(smem);
   double2* s_beams = reinterpret_cast<double2*>(smem + (((size_t)table_lds_len * sizeof(double) + 15) & ~(size_t)15));
+  // HOST_MODE 2: 4 waves x 16 records behind the beams (the launch asks for 2 KB more)
+  double4* s_rec = reinterpret_cast<double4*>(reinterpret_cast<unsigned char*>(s_beams) +
+                                              (((size_t)A.n_beams * sizeof(double2) + 31) & ~(size_t)31));
+  (void)s_rec;
 
   const int tid = threadIdx.x;
   // staging: all of a thread's loads are issued before the first LDS store, so their latencies overlap
@@ -279,7 +294,19 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
     const int cnt = min(16, p_end - base);
     // one coalesced load brings the 16 particles' (Qx, Qy, cos, sin); each is then broadcast to the
     // wave through scalar registers (a scalar load per particle would expose its latency 16 times)
-    const double4 ql = A.prep[base + min(lane & 15, cnt - 1)];
+    double4 ql;
+    if (HOST_REC)
+    {
+      // lane k (and its copies k + 16, 32, 48) reads record k of the trip; lanes < 16 park it in the wave's LDS stash
+      // for the epilogue instead of holding eight more registers through the trip
+      const double4 rec = A.rec[base + min(lane & 15, cnt - 1)];
+      bool valid;
+      ql = field_prep_of(M, rec.x, rec.y, rec.z, A.sp_x, A.sp_y, A.sp_th, &valid);
+      if (lane < 16)
+        s_rec[wave * 16 + lane] = rec;
+    }
+    else
+      ql = A.prep[base + min(lane & 15, cnt - 1)];
     double mine = 0.0;
     if (!COUNT_ONLY)
     {
@@ -415,12 +442,24 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
       else  // prob: exp(sum log pz)
         p = exp(sum);
       const int i = base + lane;
-      double w = A.p.w[i] * p;
-      w *= recalc_factor(M, A.p.x[i], A.p.y[i], A.off_map_factor, A.non_free_factor, A.non_free_radius);
-      A.p.w[i] = w;
-      if (HOST_OUT)  // plain stores: 16 neighbouring weights leave as one 128-byte write (a system-scope atomic store
-        A.w_host[i] = w;  // per lane is its own PCIe packet: 50 k of them backed up for 25 us behind the launch)
-      wsum += w;
+      if (HOST_REC)
+      {
+        double4 rec = s_rec[wave * 16 + lane];
+        double w = rec.w * p;
+        w *= recalc_factor(M, rec.x, rec.y, A.off_map_factor, A.non_free_factor, A.non_free_radius);
+        rec.w = w;
+        A.rec[i] = rec;
+        wsum += w;
+      }
+      else
+      {
+        double w = A.p.w[i] * p;
+        w *= recalc_factor(M, A.p.x[i], A.p.y[i], A.off_map_factor, A.non_free_factor, A.non_free_radius);
+        A.p.w[i] = w;
+        if (HOST_OUT)  // plain stores: 16 neighbouring weights leave as one 128-byte write (a system-scope atomic
+          A.w_host[i] = w;  // store per lane is its own PCIe packet: 50 k of them backed up for 25 us behind the launch)
+        wsum += w;
+      }
     }
     PHASE_MARK(4);  // epilogue
   }

@@ -113,7 +113,8 @@ class Engine:
         return a.value
 
     def seam_last_plan(self):
-        """(chunks, pinned) of the last applyModelToSampleSet: 0 chunks = the plain upload / score / download."""
+        """(chunks, pinned) of the last applyModelToSampleSet: 0 chunks = the plain upload / score / download, -1 = one
+        launch that read and wrote the registered records in place."""
         a, b = C.c_int(), C.c_int()
         self.check(self.lib.bpf_seam_last_plan(self.h, C.byref(a), C.byref(b)))
         return a.value, bool(b.value)

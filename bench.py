@@ -721,10 +721,13 @@ def host_buffer_path(wl, sc, pf, data):
         e.unregisterHostBuffer(host_samples)
     evals = float(wl["n"]) * wl["beams"]
     return {"ms_per_update": dth * 1e3, "evals_per_s": evals / dth,
-            "what": "applyModelToSampleSet on a host-resident set registered once (bpf_host_buffer_register): %.1f MB of "
-                    "records up in %d chunks on a copy stream, chunk k scored while chunk k + 1 crosses PCIe, the %.1f MB "
-                    "of weights stored into pinned host memory by the scoring launches and written into the records "
-                    "chunk by chunk" % (wl["n"] * 32 / 1e6, chunks, wl["n"] * 8 / 1e6),
+            "what": ("applyModelToSampleSet on a host-resident set registered once (bpf_host_buffer_register): ONE scoring "
+                     "launch reads the %.1f MB of records over PCIe itself as its waves reach them and writes them back "
+                     "whole with the new weight; no copy, nothing left for the calling thread but to wait"
+                     % (wl["n"] * 32 / 1e6)) if chunks < 0 else
+                    ("applyModelToSampleSet on a host-resident set registered once: %.1f MB of records up in %d chunks, "
+                     "chunk k scored while chunk k + 1 crosses PCIe, the weights stored into pinned host memory by the "
+                     "scoring launches and written into the records chunk by chunk" % (wl["n"] * 32 / 1e6, chunks)),
             "pinned": bool(pinned), "chunks": chunks,
             "ms_per_update_unregistered": d_plain * 1e3,
             # the whole cycle with the set crossing PCIe both ways (SURVEY 8(d)'s end-to-end figure): H2D of the set

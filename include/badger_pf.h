@@ -121,7 +121,8 @@ int bpf_host_buffer_is_registered(bpf_engine* e, const void* ptr, size_t bytes);
  * pair per level (also after the pieces declined a stream), 3 = the persistent launch, 0 = none yet */
 int bpf_kld_last_form(bpf_engine* e, int* form_out);
 /* what the last bpf_planar_apply_model_to_sample_set did: chunks of the pipelined form (0 = the plain upload / score /
- * download sequence); pinned = the buffer lies in a registered range */
+ * download sequence, -1 = one scoring launch that read and wrote the registered records in place); pinned = the buffer
+ * lies in a registered range */
 int bpf_seam_last_plan(bpf_engine* e, int* chunks_out, int* pinned_out);
 
 /* ------------------------------------------------------------------ planar scanner

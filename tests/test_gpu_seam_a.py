@@ -41,7 +41,8 @@ def _check(got, total, big):
     assert abs(total - big["want_total"]) <= 1e-9 * abs(big["want_total"])
 
 
-BIG_CHUNKS = 2  # sets of 40 000 particles or more go through in two chunks
+BIG_CHUNKS = 2  # sets of 40 000 particles or more go through in two chunks ...
+IN_PLACE = -1   # ... unless the buffer is registered (and 16-byte aligned): one launch reads and writes the records in place
 
 
 def test_pipelined_form_equals_the_plain_sequence_and_the_oracle(engine, big):
@@ -64,7 +65,8 @@ def test_pipelined_form_equals_the_plain_sequence_and_the_oracle(engine, big):
                 try:
                     buf[:] = sc_.samples
                     total = sc.applyModelToSampleSet(data, buf, 0)
-                    assert engine.seam_last_plan() == (chunks or BIG_CHUNKS, pinned)
+                    want_plan = IN_PLACE if (pinned and chunks == 0) else (chunks or BIG_CHUNKS)
+                    assert engine.seam_last_plan() == (want_plan, pinned)
                 finally:
                     engine.set_option(bpf.pf.OPT_SEAM_CHUNKS, 0)
                 # same kernels on the same particles: the weights are the same bits; the total is the sum of the
@@ -83,12 +85,12 @@ def test_registered_buffer(engine, big):
         for _ in range(3):
             buf[:] = sc_.samples
             total = sc.applyModelToSampleSet(data, buf, 0)
-            assert engine.seam_last_plan() == (BIG_CHUNKS, True)
+            assert engine.seam_last_plan() == (IN_PLACE, True)
             _check(buf, total, big)
         # the live prefix of a registered buffer (sample_count < max_samples) is read as pinned memory too
         buf[:] = sc_.samples
         sc.applyModelToSampleSet(data, buf[:40000], 0)
-        assert engine.seam_last_plan() == (2, True)
+        assert engine.seam_last_plan() == (IN_PLACE, True)
         assert np.array_equal(buf[40000:], sc_.samples[40000:])
         assert rel_err(buf[:40000, 3], big["want"][:40000, 3]).max() <= W_TOL
         # the filter's own host-buffer calls take the same registration
@@ -114,13 +116,14 @@ def test_unregistered_unaligned_buffer(engine, big):
         total = sc.applyModelToSampleSet(data, got, 0)
         assert engine.seam_last_plan() == (BIG_CHUNKS, False)
         _check(got, total, big)
-    # ... and the same unaligned range, registered
+    # ... and the same unaligned range, registered: pinned for the copy engine, but not read in place (the in-place
+    # launch moves the records as 16-byte pairs)
     got = raw[1:1 + 4 * n].reshape(n, 4)
     got[:] = sc_.samples
     engine.registerHostBuffer(got)
     try:
         total = sc.applyModelToSampleSet(data, got, 0)
-        assert engine.seam_last_plan() == (BIG_CHUNKS, True)
+        assert engine.seam_last_plan() == ((IN_PLACE if got.ctypes.data % 16 == 0 else BIG_CHUNKS), True)
         _check(got, total, big)
     finally:
         engine.unregisterHostBuffer(got)
@@ -134,7 +137,7 @@ def test_a_buffer_that_moves_between_calls(engine, big):
     a = sc_.samples.copy()
     engine.registerHostBuffer(a)
     total = sc.applyModelToSampleSet(data, a, 0)
-    assert engine.seam_last_plan() == (BIG_CHUNKS, True)
+    assert engine.seam_last_plan() == (IN_PLACE, True)
     _check(a, total, big)
     addr_a = a.ctypes.data
     b = sc_.samples.copy()
@@ -165,7 +168,7 @@ def test_auto_registration_is_opt_in(engine, big):
     try:
         buf[:] = sc_.samples
         total = sc.applyModelToSampleSet(data, buf, 0)
-        assert engine.seam_last_plan() == (BIG_CHUNKS, True) and engine.isHostBufferRegistered(buf)
+        assert engine.seam_last_plan() == (IN_PLACE, True) and engine.isHostBufferRegistered(buf)
         _check(buf, total, big)
         buf[:] = sc_.samples
         total = sc.applyModelToSampleSet(data, buf, 0)
@@ -185,7 +188,7 @@ def test_pipelined_form_other_field_models(engine, orc, model):
     engine.registerHostBuffer(got)
     try:
         total = sc.applyModelToSampleSet(data, got, 0)
-        assert engine.seam_last_plan() == (2, True)
+        assert engine.seam_last_plan() == (IN_PLACE, True)
     finally:
         engine.unregisterHostBuffer(got)
     bad = rel_err(got[:, 3], want[:, 3]) > W_TOL

@@ -14,7 +14,7 @@ sc.setMapFactors(*synth.MAP_FACTORS); sc.setPlanarScannerPose(synth.SCANNER_POSE
 data = bpf.PlanarData(ranges, angles, 30.0)
 s0 = synth.converged_cloud(n, pose); buf = s0.copy()
 e.registerHostBuffer(buf)
-for ch in (2,):
+for ch in (0,):
     e.set_option(12, ch)
     for _ in range(300): sc.applyModelToSampleSet(data, buf, 0)
     for _ in range(3): sc.applyModelToSampleSet(data, buf, 0)
