@@ -50,7 +50,9 @@ def build(force=False, verbose=False):
     build_rccl(force, verbose)
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+    # BPF_EXTRA_FLAGS: experiment builds (e.g. "-DBPF_FIELD_UNROLL=4 -DBPF_FIELD_WAVES=5"); not used by the product
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + \
+        os.environ.get("BPF_EXTRA_FLAGS", "").split() + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
