@@ -83,6 +83,7 @@ SIGNATURES = {
     "bpf_host_buffer_is_registered": (C.c_int, [_vp, C.c_void_p, C.c_size_t]),
     "bpf_seam_last_plan": (C.c_int, [_vp, _ip, _ip]),
     "bpf_kld_last_form": (C.c_int, [_vp, _ip]),
+    "bpf_score_last_form": (C.c_int, [_vp, _ip]),
     "bpf_wire_laserscan_to_planar": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_double,
                                                C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]),
     "bpf_wire_scan_angle_stats": (C.c_int, [C.c_double, C.c_double, _dp, _dp, _dp]),

@@ -119,6 +119,7 @@ int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, i
   e->converged_pending = false;
   e->fused_partials = 0;
   e->tree_pending = false;
+  e->spread_init = false;
   if (leaf_count >= 0)
   {
     e->leaf_count = leaf_count;
@@ -325,6 +326,7 @@ int bpf_pf_update_resample(bpf_engine* e)
       return rc;
   }
   e->tree_pending = false;  // the multinomial resampler builds the new set's tree from its draws
+  e->spread_init = false;   // from here on the resample's own outcome says whether the cloud is spread
   rc = build_cdf(e, a.w.p, e->sample_count);
   if (rc != BPF_OK)
     return rc;

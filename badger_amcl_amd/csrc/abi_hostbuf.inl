@@ -131,6 +131,14 @@ int bpf_host_buffer_is_registered(bpf_engine* e, const void* ptr, size_t bytes)
   return host_reg_find(e, ptr, bytes) != nullptr ? 1 : 0;
 }
 
+int bpf_score_last_form(bpf_engine* e, int* form_out)
+{
+  if (!e || !form_out)
+    return BPF_ERR_INVALID_ARGUMENT;
+  *form_out = e->last_score_form;
+  return BPF_OK;
+}
+
 int bpf_kld_last_form(bpf_engine* e, int* form_out)
 {
   if (!e || !form_out)

@@ -277,6 +277,7 @@ int bpf_pf_init_with_random_poses(bpf_engine* e)
                      e->rng, e->jump, fs, 1.0 / (double)n);
   HIPCHK(e, hipGetLastError());
   e->rng = lcg_skip_host(e->rng, 2ull * (uint64_t)n, e->jump);
+  e->spread_init = true;  // uniform over the free space: scored in tile order until a resample says otherwise
   return finish_init(e, n);
 }
 

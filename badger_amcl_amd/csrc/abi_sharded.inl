@@ -917,6 +917,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->kld_persistent = value != 0;
   else if (option == BPF_OPT_KLD_LOCAL)
     e->kld_local = value != 0;
+  else if (option == BPF_OPT_TILE_SORT)
+    e->tile_sort = value != 0;
   else if (option == BPF_OPT_STATS_HOST)
   {
     e->stats_host = value != 0;

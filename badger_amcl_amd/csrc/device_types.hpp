@@ -71,6 +71,8 @@ struct FieldScoreArgs
   int share_count[8];
   int share_base[8];
   int blocks_per_round;
+  int xcd_local;             // graded partition: the eighth of the particle range of a block's XCD (see the kernel)
+  const int* perm;           // HOST_MODE 3 (tile-sorted scoring): particle of slot j
   int model;
   GompertzDev g;
   int n_valid;               // beams that count towards the Gompertz mean

@@ -410,6 +410,13 @@ struct bpf_engine
   bool last_seam_registered = false;
   bool tree_pending = false;        // the current set's histogram tree (leaf / bin counts) has not been built yet
 
+  // ---- tile-sorted scoring of a spread cloud (kernels_window.hpp, HOST_MODE 3 of k_score_field)
+  bool tile_sort = true;            // BPF_OPT_TILE_SORT
+  bool spread_init = false;         // the set was initialised with uniform random poses and not resampled since
+  DevBuf<int> d_tile_int;           // hist[kTileBins] cursor[kTileBins] tile[n] perm[n]
+  DevBuf<double4> d_prep_sorted;
+  int last_score_form = 0;          // diagnostics: 3 = the last scoring launch walked the particles in tile order
+
   // ---- profiling
   bool profiling = false;
   unsigned timed_launches = 0;  // scoring launches seen in profile mode 1 / 3 (every timed_stride-th is timed)

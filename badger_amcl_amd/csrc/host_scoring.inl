@@ -202,6 +202,15 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
   HIPCHK(e, e->d_prep.reserve((size_t)n));
   HIPCHK(e, e->d_prep_stats.reserve((size_t)prep_blocks * kPrepStats));
   const bool rec_mode = host_out != nullptr && host_out->rec != nullptr;
+  // Tile-sorted scoring (HOST_MODE 3 of k_score_field): for a cloud that the previous resample found spread (it ran to
+  // the end without a KLD stop: window_hint, as for the CDF's guide table) or that was just drawn uniformly over the
+  // map, on a map whose LUT image does not fit an XCD's L2.
+  const size_t lut_bytes = (size_t)e->map.ltx * e->map.lty * 128;
+  const bool tile_mode = e->tile_sort && want_partials && !count_only && table_lds && host_out == nullptr &&
+                         aos == nullptr && !e->window_enabled && e->graded_shares && (e->n_cu & 7) == 0 &&
+                         n >= e->n_cu * 4 * 64 && lut_bytes > ((size_t)3 << 20) &&
+                         (e->window_hint >= e->max_samples || e->spread_init);
+  e->last_score_form = 0;
   if (host_out != nullptr)
   {
     A.w_host = host_out->w_host;
@@ -226,7 +235,30 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
       HIPCHK(e, hipMemcpyAsync(s->dev.p, s->host.p, fs.bytes, hipMemcpyHostToDevice, e->stream));
     ProfScope pa(e, BPF_K_SCORE_AUX);
     const uint4* src = ride ? reinterpret_cast<const uint4*>(s->host.p) : static_cast<const uint4*>(nullptr);
-    if (aos != nullptr)
+    if (tile_mode)
+    {
+      // prep + counting sort by map tile: bins of 2^shift cells with at most 64 bins per axis
+      int shift = 5;
+      while ((((e->map.size_x + 2) >> shift) + 1) > 64 || (((e->map.size_y + 2) >> shift) + 1) > 64)
+        ++shift;
+      const int txc = ((e->map.size_x + 2) >> shift) + 1, tyc = ((e->map.size_y + 2) >> shift) + 1;
+      const bool fresh = e->d_tile_int.cap < (size_t)2 * kTileBins + 2 * (size_t)n;
+      HIPCHK(e, e->d_tile_int.reserve((size_t)2 * kTileBins + 2 * (size_t)n));
+      HIPCHK(e, e->d_prep_sorted.reserve((size_t)n));
+      int* hist = e->d_tile_int.p;
+      int* cursor = hist + kTileBins;
+      int* tile = cursor + kTileBins;
+      int* perm = tile + n;
+      if (fresh)  // the offsets launch leaves the counts at zero for the next scan
+        HIPCHK(e, hipMemsetAsync(hist, 0, kTileBins * sizeof(int), e->stream));
+      hipLaunchKernelGGL(k_field_prep_tile, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
+                         A.sp_th, e->d_prep.p, tile, hist, shift, txc, tyc, src, reinterpret_cast<uint4*>(s->dev.p), n16);
+      hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, e->stream, hist, cursor);
+      hipLaunchKernelGGL(k_tile_scatter, dim3(prep_blocks), dim3(256), 0, e->stream, n, (const int*)tile, cursor,
+                         (const double4*)e->d_prep.p, perm, e->d_prep_sorted.p);
+      A.perm = perm;
+    }
+    else if (aos != nullptr)
       hipLaunchKernelGGL(k_field_prep_aos, dim3(prep_blocks), dim3(256), 0, e->stream, aos, p, n, e->map, A.sp_x, A.sp_y,
                          A.sp_th, e->d_prep.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
     else if (e->window_enabled)
@@ -236,13 +268,14 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
       hipLaunchKernelGGL(k_field_prep<false>, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
                          A.sp_th, e->d_prep.p, e->d_prep_stats.p, src, reinterpret_cast<uint4*>(s->dev.p), n16);
   }
-  A.prep = e->d_prep.p;
+  A.prep = tile_mode ? e->d_prep_sorted.p : e->d_prep.p;
   // One resident round: blocks per CU = what registers, LDS and the SGPR rule admit (the occupancy
   // API can over-report by one block for SGPR-heavy kernels: MI355X_MICROARCH.md, residency).
   int api_blocks = 0;
   if (host_out != nullptr && (count_only || !table_lds))
     return e->fail(BPF_ERR_UNSUPPORTED, "host-out scoring kernel: table-in-LDS scoring form only");
   const void* kfn = count_only ? reinterpret_cast<const void*>(&k_score_field<true, false>)
+                               : tile_mode ? reinterpret_cast<const void*>(&k_score_field<false, true, 3>)
                                : (rec_mode ? reinterpret_cast<const void*>(&k_score_field<false, true, 2>)
                                   : host_out != nullptr ? reinterpret_cast<const void*>(&k_score_field<false, true, 1>)
                                   : (table_lds ? reinterpret_cast<const void*>(&k_score_field<false, true>)
@@ -274,13 +307,26 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
       base += A.share_count[k] * e->n_cu * 4;
     }
     grid = e->n_cu * per_cu;
+    A.xcd_local = tile_mode ? 1 : 0;
+  }
+  const bool tile_run = tile_mode && A.xcd_local != 0;  // (the graded partition applies: four blocks per CU)
+  if (tile_mode && !tile_run)
+  {
+    // the occupancy came out differently: walk the slots in tile order all the same, without the XCD-wise split
+    A.xcd_local = 0;
   }
   if (host_out != nullptr && grid > kSeamMaxBlocks)
     return e->fail(BPF_ERR_CAPACITY, "host-out scoring launch: more blocks than the partials buffer holds");
   A.block_partials = host_out != nullptr ? host_out->partials : nullptr;
   A.skip_if_set = nullptr;
   e->last_used_window_path = false;
-  if (want_partials && !count_only)
+  if (tile_mode)
+  {
+    // no block partials: which particles share a block depends on the order inside a tile (atomics); the total is a
+    // fixed-shape sum over the weights in index order, launched behind the scoring kernel below
+    A.block_partials = nullptr;
+  }
+  else if (want_partials && !count_only)
   {
     HIPCHK(e, e->d_block_partials.reserve((size_t)grid));
     A.block_partials = e->d_block_partials.p;
@@ -353,6 +399,16 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
       LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true, 1>), dim3(grid), dim3(256), lds, A);
     hipLaunchKernelGGL(k_seam_done, dim3(1), dim3(256), 0, e->stream, (const double*)host_out->partials, grid,
                        host_out->total_host, host_out->flag, host_out->value);
+  }
+  else if (tile_mode)
+  {
+    LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true, 3>), dim3(grid), dim3(256), lds, A);
+    const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+    HIPCHK(e, e->d_block_partials.reserve((size_t)nb));
+    hipLaunchKernelGGL(k_sum_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, (const double*)p.w, n,
+                       e->d_block_partials.p);
+    e->fused_partials = nb;  // the normalise launch folds these instead of the scoring kernel's
+    e->last_score_form = 3;
   }
   else if (table_lds)
     LAUNCH_TIMED(e, BPF_K_SCORE, (k_score_field<false, true>), dim3(grid), dim3(256), lds, A);

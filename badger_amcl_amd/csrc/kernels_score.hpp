@@ -207,6 +207,16 @@ __device__ unsigned long long g_phase_cycles[kPhaseWaves][8];
 // serialise -- a 50 k-particle launch took 75 us instead of 40 -- and a system-scope release per block costs an L2
 // write-back each.)
 //
+// HOST_MODE 3 has nothing to do with the host: TILE-SORTED scoring of a spread cloud.  With the particles all over the
+// map every XCD's 4 MB L2 sees the whole LUT (8.3 MB for a 2000 x 2000 map): 747 MB of L2 fills per launch against
+// 436 MB algorithmic, 6.3 TB/s, and the kernel waits for LUT lines (120 us where the converged cloud takes 73).  The
+// prep launch therefore also bins the particles by map tile (k_field_prep_tile, k_tile_offsets, k_tile_scatter: a
+// counting sort into A.perm, prep values written in that order), this kernel walks slots in tile order and the
+// graded partition hands each XCD -- blocks b and b + 8 share one -- a CONTIGUOUS eighth of the slots (A.xcd_local),
+// i.e. an eighth of the map: its L2 then holds what its waves gather from.  85 us.  The order of the slots changes
+// nothing in a particle's own arithmetic; the total comes from a fixed-shape sum over the weights in index order
+// (no block partials in this mode), so the result does not depend on the order inside a tile either.
+//
 // HOST_MODE 2 (a REGISTERED buffer): no copy at all -- every wave reads the caller's 32-byte records from host memory
 // itself when it reaches them (A.rec, zero-copy over PCIe), forms (Qx, Qy, cos, sin) with the prep launch's own
 // function, and writes the records back WHOLE with the new weight (16 neighbouring records = 512 contiguous bytes per
@@ -220,6 +230,7 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
 {
   constexpr bool HOST_OUT = HOST_MODE == 1;
   constexpr bool HOST_REC = HOST_MODE == 2;
+  constexpr bool TILE_ORDER = HOST_MODE == 3;  // slot j of the launch is particle A.perm[j] (tile-sorted scoring)
 #ifdef BPF_PHASE_TIMING
   unsigned long long _ph[6] = { 0, 0, 0, 0, 0, 0 };
   long long _t = clock64();
@@ -285,8 +296,29 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
     // blockIdx order, n_cu per round, so the round a block belongs to tells its age rank on its CU and the
     // shares are graded by it (tools/phase_timing.py shows the effect: every wave then ends within 70-80 us).
     const int round = min((int)blockIdx.x / A.blocks_per_round, 7);
-    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - round * A.blocks_per_round) * 4 + wave);
-    p_begin = min(A.n, A.share_base[round] + slot * A.share_count[round]);
+    const int q = (int)blockIdx.x - round * A.blocks_per_round;
+    if (A.xcd_local)
+    {
+      // Blocks b and b + 8 share an XCD (and its 4 MB L2): the x-th eighth of the particle range goes to the blocks
+      // with b % 8 == x, split over the placement rounds by the same shares.  With the particles ordered by map tile
+      // (tile-sorted scoring of a spread cloud) an XCD then only ever sees its own eighth of the map's LUT.
+      const int x = q & 7, cu_slot = q >> 3, per_x = A.blocks_per_round >> 3;
+      int xcd_total = 0, before = 0;
+      for (int r = 0; r < 8; ++r)
+      {
+        const int c = A.share_count[r] * per_x * 4;
+        xcd_total += c;
+        if (r < round)
+          before += c;
+      }
+      const int slot = __builtin_amdgcn_readfirstlane(cu_slot * 4 + wave);
+      p_begin = min(A.n, x * xcd_total + before + slot * A.share_count[round]);
+    }
+    else
+    {
+      const int slot = __builtin_amdgcn_readfirstlane(q * 4 + wave);
+      p_begin = min(A.n, A.share_base[round] + slot * A.share_count[round]);
+    }
     p_end = min(A.n, p_begin + A.share_count[round]);
   }
   for (int base = p_begin; base < p_end; base += 16)
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(256, BPF_FIELD_WAVES) void k_score_field(const Fiel
       }
       else  // prob: exp(sum log pz)
         p = exp(sum);
-      const int i = base + lane;
+      const int i = TILE_ORDER ? A.perm[base + lane] : base + lane;
       if (HOST_REC)
       {
         double4 rec = s_rec[wave * 16 + lane];

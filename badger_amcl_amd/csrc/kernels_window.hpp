@@ -117,6 +117,108 @@ __global__ __launch_bounds__(256) void k_field_prep_aos(const double4* __restric
 }
 
 // ---------------------------------------------------------------------------------------
+// Tile-sorted scoring of a spread cloud (HOST_MODE 3 of k_score_field): a counting sort of the particles by the map
+// tile of their scanner position.  kTileBins bins of 2^shift x 2^shift cells, row-major, so that an eighth of the
+// sorted order is an eighth of the map's rows.
+constexpr int kTileBins = 4096;
+
+__device__ __forceinline__ int tile_of(const double4 q, int shift, int tx_count, int ty_count)
+{
+  const int cx = min(max((int)q.x, 0) >> shift, tx_count - 1);
+  const int cy = min(max((int)q.y, 0) >> shift, ty_count - 1);
+  return cy * tx_count + cx;
+}
+
+// One atomic per lane -- a spread cloud's 64 lanes hit (nearly) 64 different bins, and the atomics of a wave overlap --
+// except when the whole wave sits in ONE bin (a cloud that is not spread after all: 10^5 atomics on a handful of
+// addresses would serialise): then the first lane adds the count.  Returns the lane's position in its bin.
+__device__ __forceinline__ int wave_bin_add(int* counters, int bin, bool active)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned long long act = __ballot(active);
+  if (act == 0ull)
+    return 0;
+  const int leader = __ffsll((long long)act) - 1;
+  const int b0 = __shfl(bin, leader, 64);
+  if (__ballot(active && bin == b0) == act)
+  {
+    int prev = 0;
+    if (lane == leader)
+      prev = atomicAdd(&counters[b0], __popcll(act));
+    return __shfl(prev, leader, 64) + __popcll(act & ((1ull << lane) - 1ull));
+  }
+  return active ? atomicAdd(&counters[bin], 1) : 0;
+}
+
+__global__ __launch_bounds__(256) void k_field_prep_tile(ParticlesDev p, int n, MapDev M, double ax, double ay, double ath,
+                                                        double4* __restrict__ prep, int* __restrict__ tile,
+                                                        int* __restrict__ hist, int shift, int tx_count, int ty_count,
+                                                        const uint4* __restrict__ stage_src,
+                                                        uint4* __restrict__ stage_dst, int stage_n16)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (stage_src != nullptr && i < stage_n16)
+    stage_dst[i] = stage_src[i];
+  int t = 0;
+  if (i < n)
+  {
+    bool valid;
+    const double4 q = field_prep_of(M, p.x[i], p.y[i], p.th[i], ax, ay, ath, &valid);
+    prep[i] = q;
+    t = tile_of(q, shift, tx_count, ty_count);
+    tile[i] = t;
+  }
+  (void)wave_bin_add(hist, t, i < n);
+}
+
+// one block: exclusive prefix of the bin counts; the counts are left at zero for the next scan, the cursors at the
+// bins' offsets
+__global__ __launch_bounds__(1024) void k_tile_offsets(int* __restrict__ hist, int* __restrict__ cursor)
+{
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  constexpr int per = kTileBins / 1024;
+  int v[per], sum = 0;
+#pragma unroll
+  for (int q = 0; q < per; ++q)
+  {
+    v[q] = hist[tid * per + q];
+    sum += v[q];
+    hist[tid * per + q] = 0;
+  }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1)
+  {
+    const int u = tid >= o ? s_part[tid - o] : 0;
+    __syncthreads();
+    s_part[tid] += u;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;
+#pragma unroll
+  for (int q = 0; q < per; ++q)
+  {
+    cursor[tid * per + q] = run;
+    run += v[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_tile_scatter(int n, const int* __restrict__ tile, int* __restrict__ cursor,
+                                                     const double4* __restrict__ prep, int* __restrict__ perm,
+                                                     double4* __restrict__ prep_sorted)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int t = i < n ? tile[i] : 0;
+  const int pos = wave_bin_add(cursor, t, i < n);
+  if (i < n)
+  {
+    perm[pos] = i;
+    prep_sorted[pos] = prep[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_field_windows(const double* __restrict__ stats, int n_stat_blocks,
                                                        const double2* __restrict__ beams, int n_beams, MapDev M,
                                                        WindowPlan* plan)

@@ -32,6 +32,7 @@ OPT_LUT_EXACT_EDT = 10
 OPT_HOST_AUTO_REGISTER = 11
 OPT_SEAM_CHUNKS = 12
 OPT_KLD_LOCAL = 13
+OPT_TILE_SORT = 14
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 
@@ -105,6 +106,12 @@ class Engine:
 
     def isHostBufferRegistered(self, array):
         return bool(self.lib.bpf_host_buffer_is_registered(self.h, C.c_void_p(array.ctypes.data), array.nbytes))
+
+    def score_last_form(self):
+        """3 = the last scoring launch of a resident set walked the particles in map-tile order, 0 = index order."""
+        a = C.c_int()
+        self.check(self.lib.bpf_score_last_form(self.h, C.byref(a)))
+        return a.value
 
     def kld_last_form(self):
         """2 = the last device-side histogram tree was grown in LDS-sized pieces, 1 = level loop, 3 = persistent."""

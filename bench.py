@@ -406,6 +406,12 @@ def pmc_evidence(model, cloud, k_ms, n, beams):
     if rec.get("issue_frac") is not None:
         out["issue_frac"] = rec["issue_frac"]  # SQ_ACTIVE_INST_VALU x 4 cycles / SIMDs / kernel cycles, that run
         out["bound"] = rec.get("bound", "valu_issue")
+    if out.get("hbm_measured_gbs", 0.0) >= 0.5 * HBM_PEAK_GBS:
+        # the L2s fetch at more than half the HBM peak (FETCH_SIZE counts every L2 fill, Infinity-Cache hits included):
+        # the spread cloud, whose particles put the whole LUT through every XCD's 4 MB L2
+        out["bound"] = "hbm"
+        out["bound_is"] = ("L2 fills (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included) above half the HBM "
+                           "peak: the kernel waits for LUT lines, not for issue slots")
     return out
 
 
@@ -642,6 +648,8 @@ def measure(args, ctx, steps, warmup, prewarm, cpu_budget, all_cores=False, host
     }
     if ev["bound"] is None:
         line["roofline"]["bound_is"] = "unmeasured: no committed PMC pass for this workload (profiles/pmc_traffic.json)"
+    elif "bound_is" in ev:
+        line["roofline"]["bound_is"] = ev["bound_is"]
     for k in ("issue_frac", "hbm_measured_gbs"):
         if k in ev:
             line["roofline"][k] = ev[k]

@@ -117,6 +117,9 @@ int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist);
 int bpf_host_buffer_register(bpf_engine* e, void* ptr, size_t bytes);
 int bpf_host_buffer_unregister(bpf_engine* e, void* ptr);
 int bpf_host_buffer_is_registered(bpf_engine* e, const void* ptr, size_t bytes);
+/* 3 when the last likelihood-field scoring launch of a resident set walked the particles in map-tile order
+ * (BPF_OPT_TILE_SORT), 0 otherwise */
+int bpf_score_last_form(bpf_engine* e, int* form_out);
 /* which form the last device-side histogram tree took: 2 = grown in LDS-sized pieces (kernels_kld2.hpp), 1 = one launch
  * pair per level (also after the pieces declined a stream), 3 = the persistent launch, 0 = none yet */
 int bpf_kld_last_form(bpf_engine* e, int* form_out);
@@ -249,6 +252,10 @@ enum
                                * (one block grows the top from the first 2 048 keys, the later keys are routed through it
                                * and blocks grow the subtrees below its nodes: kernels_kld2.hpp) instead of one launch
                                * pair per level; 0 = the level loop.  Same tree. */
+  BPF_OPT_TILE_SORT = 14,     /* default 1: a cloud the previous resample found spread (no KLD stop) or that was just drawn
+                               * uniformly is scored in map-tile order, each XCD taking a contiguous eighth of it, when the
+                               * map's LUT does not fit an XCD's L2 (tile-sorted scoring); 0 = index
+                               * order always.  Same weights. */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.

@@ -79,11 +79,17 @@ def test_pmc_evidence_is_only_attached_to_the_workload_it_was_measured_on():
     ev = bench.pmc_evidence("lf", "converged", 0.0737, 100000, 1081)
     assert ev["bound"] == "valu_issue" and ev["traffic"] and "static" in ev["traffic_source"]
     assert 0.3 < ev["issue_frac"] < 1.1 and ev["hbm_measured_gbs"] > 0
-    other = bench.pmc_evidence("lf", "converged", 0.0737, 5000, 181)
+    other = bench.pmc_evidence("lf", "converged", 0.0737, 7777, 181)
     assert other["traffic"] is None and "issue_frac" not in other
     # ... and without a record NOTHING is claimed about what binds the kernel (it used to say "hbm")
     assert other["bound"] is None
     assert bench.pmc_evidence("lf", "spread", 0.12, 123456, 1081)["bound"] is None
+    # round 3: the spread cloud, 125 k, 1 M and cfg 1 have passes of their own, keyed by size where the key needs it
+    sp = bench.pmc_evidence("lf", "spread", 0.119, 100000, 1081)
+    assert sp["bound"] == "hbm" and sp["hbm_measured_gbs"] > 5000 and sp["traffic"] > 436.4e6  # L2 fills > algorithmic
+    assert bench.pmc_evidence("lf", "converged", 0.089, 125000, 1081)["bound"] == "valu_issue"
+    assert bench.pmc_evidence("lf", "converged", 0.66, 1000000, 1081)["bound"] == "valu_issue"
+    assert bench.pmc_evidence("lf", "converged", 0.0095, 5000, 181)["bound"] == "latency"
 
 
 def test_plain_headline_detection_and_sub_records():

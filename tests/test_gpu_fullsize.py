@@ -317,3 +317,42 @@ def test_one_million_particles_on_one_gpu(engine, world, orc):
 
 def rel_max(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def test_tile_sorted_scoring_of_a_spread_cloud_gives_the_same_weights(engine, world):
+    """A cloud the previous resample found spread is scored in map-tile order with each XCD taking a contiguous eighth
+    of it (HOST_MODE 3 of k_score_field).  Nothing in a particle's own arithmetic depends on the order: the weights
+    equal the index-order weights up to the rounding of the one division by the total (whose summation shape differs),
+    and the resample that follows picks the same particles."""
+    import badger_amcl_amd as bpf
+    n = 100000
+    samples = synth.spread_cloud(n, world["size"], seed=77, margin=0.5)
+    sc, data = world["sc"], world["data"]
+    out = {}
+    for mode in (0, 1):
+        engine.set_option(bpf.pf.OPT_TILE_SORT, mode)
+        try:
+            pf = bpf.ParticleFilter(engine, 100, n, 0.0, 0.0, 85.0)  # a new filter: no resample has said "spread" yet
+            pf.srand48(5)
+            pf.initWithSamples(samples)
+            sc.updateSensor(pf, data)
+            assert engine.score_last_form() == 0   # nothing says "spread" yet
+            pf.updateResample()                     # runs to the end: no KLD stop for a spread cloud
+            assert pf.getState().sample_count == n
+            pf.srand48(5)
+            pf.initWithSamples(samples)
+            sc.updateSensor(pf, data)
+            assert engine.score_last_form() == (3 if mode else 0)
+            w = pf.getCurrentSet().samples[:, 3].copy()
+            st = pf.getState()
+            pf.updateResample()
+            out[mode] = (w, st.total, pf.getCurrentSet().samples.copy(), pf.getState())
+        finally:
+            engine.set_option(bpf.pf.OPT_TILE_SORT, 1)
+    w0, t0, set0, st0 = out[0]
+    w1, t1, set1, st1 = out[1]
+    assert abs(t1 - t0) <= 1e-13 * abs(t0)
+    assert np.max(np.abs(w1 - w0) / w0) <= 1e-14
+    assert abs(w1.sum() - 1.0) < 1e-12
+    assert (st1.sample_count, st1.leaf_count) == (st0.sample_count, st0.leaf_count)
+    assert np.array_equal(set1[:, :3], set0[:, :3])
