@@ -139,16 +139,15 @@ int launch_converged(bpf_engine* e)
 {
   SampleSet& s = e->sets[e->cur];
   const int n = e->sample_count;
-  int rcode = sum_into_slot(e, s.x.p, n, 3, 0, n);
-  if (rcode != BPF_OK)
-    return rcode;
-  rcode = sum_into_slot(e, s.y.p, n, 4, 0, n);
-  if (rcode != BPF_OK)
-    return rcode;
-  HIPCHK(e, hipMemsetAsync(e->d_flags.p + 1, 0, sizeof(int), e->stream));
+  const int nb = std::max(1, blocks_for(n, BPF_RED_TILE));
+  HIPCHK(e, e->d_partials.reserve((size_t)2 * nb));
   const int grid = std::max(1, std::min(blocks_for(n, 256), 1024));
-  hipLaunchKernelGGL(k_count_converged, dim3(grid), dim3(256), 0, e->stream, s.x.p, s.y.p, n, e->d_scalars.p,
-                     e->dist_threshold, e->d_flags.p + 1);
+  ProfScope ps(e, BPF_K_FINALIZE);
+  hipLaunchKernelGGL(k_sum_xy_partials, dim3(nb), dim3(BPF_RED_BLOCK), 0, e->stream, (const double*)s.x.p,
+                     (const double*)s.y.p, n, e->d_partials.p, e->d_partials.p + nb, e->d_flags.p + 1);
+  hipLaunchKernelGGL(k_converged_count, dim3(grid), dim3(BPF_RED_BLOCK), 0, e->stream, (const double*)s.x.p,
+                     (const double*)s.y.p, n, (const double*)e->d_partials.p, (const double*)(e->d_partials.p + nb), nb,
+                     e->d_scalars.p, e->dist_threshold, e->d_flags.p + 1);
   HIPCHK(e, hipGetLastError());
   e->converged_pending = true;
   e->conv_n = n;

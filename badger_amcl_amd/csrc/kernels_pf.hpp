@@ -1212,6 +1212,73 @@ __global__ __launch_bounds__(BPF_RED_BLOCK) void k_count_converged(const double*
     atomicAdd(count, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
 }
 
+// The same in two launches instead of six stream operations (two sums of two launches each, a memset, the count):
+// k_sum_xy_partials = k_sum_partials for x and y at once (same tiles, same shape; block 0 also zeroes the count),
+// k_converged_count = every block folds the tile partials exactly as k_sum_final does -- so the means are the same
+// bits -- and counts its share.
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_sum_xy_partials(const double* __restrict__ x,
+                                                                  const double* __restrict__ y, int n,
+                                                                  double* __restrict__ px, double* __restrict__ py,
+                                                                  int* __restrict__ count)
+{
+  __shared__ double s_wave[4];
+  const size_t base = (size_t)blockIdx.x * BPF_RED_TILE + (size_t)threadIdx.x * BPF_RED_PER_THREAD;
+  double ax = 0.0, ay = 0.0;
+#pragma unroll
+  for (int k = 0; k < BPF_RED_PER_THREAD; ++k)
+    if (base + k < (size_t)n)
+    {
+      ax += x[base + k];
+      ay += y[base + k];
+    }
+  const double tx = block_sum_256(ax, s_wave);
+  const double ty = block_sum_256(ay, s_wave);
+  if (threadIdx.x == 0)
+  {
+    px[blockIdx.x] = tx;
+    py[blockIdx.x] = ty;
+    if (blockIdx.x == 0)
+      *count = 0;
+  }
+}
+
+__global__ __launch_bounds__(BPF_RED_BLOCK) void k_converged_count(const double* __restrict__ x,
+                                                                  const double* __restrict__ y, int n,
+                                                                  const double* __restrict__ px,
+                                                                  const double* __restrict__ py, int n_partials,
+                                                                  FilterScalars* sc, double thr, int* __restrict__ count)
+{
+  __shared__ double s_wave[4];
+  __shared__ int s_cnt[4];
+  double ax = 0.0, ay = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += BPF_RED_BLOCK)
+  {
+    ax += px[i];
+    ay += py[i];
+  }
+  const double sx = block_sum_256(ax, s_wave);
+  const double sy = block_sum_256(ay, s_wave);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    sc->v[3] = sx;
+    sc->v[4] = sy;
+  }
+  const double mx = sx / n, my = sy / n;
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (fabs(x[i] - mx) <= thr && fabs(y[i] - my) <= thr)
+      c++;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    c += __shfl_xor(c, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    s_cnt[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(count, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+}
+
 // ------------------------------------------------------------------ distance LUT (exact EDT)
 // Separable capped Euclidean distance transform on the reference's integer lattice:
 // value = float(sqrt(a^2+b^2) * res) for the nearest occupied cell if sqrt(a^2+b^2) <= radius,
