@@ -77,6 +77,23 @@ int main(int argc, char** argv)
   data->ranges_ = ranges;
   data->angles_ = angles;
 
+  if (argc > 10)
+  {
+    // INTEGRATION Option 1: the set stays in a host vector that is allocated once (the reference's
+    // ParticleFilter, particle_filter.cpp:62-89), pinned once, and scored where it lies
+    auto host_set = std::make_shared<PFSampleSet>();
+    host_set->samples = init;
+    host_set->sample_count = n;
+    PinnedSamples pin(eng, host_set->samples);
+    const double total = scanner->applyModelToSampleSet(data, host_set);
+    int chunks = 0, pinned = 0;
+    bpf_seam_last_plan(eng->get(), &chunks, &pinned);
+    FILE* fh = std::fopen(argv[10], "wb");
+    std::fwrite(host_set->samples.data(), sizeof(PFSample), host_set->samples.size(), fh);
+    std::fclose(fh);
+    std::fprintf(stderr, "host set: total %.17g chunks %d pinned %d\n", total, chunks, pinned);
+  }
+
   if (!scanner->updateSensor(pf, data)) return 3;
   auto set = pf->getCurrentSet();
   FILE* f = std::fopen(argv[7], "wb");

@@ -79,3 +79,27 @@ def test_adapter_default_lut_is_the_reference_brushfire(tmp_path, orc):
     opf.update_sensor(lambda s, c: sc.oracle_apply(p, s, c))
     got_w = np.fromfile(out_w, dtype=np.float64).reshape(-1, 4)
     assert rel_err(got_w[:, 3], opf.samples[:1500, 3]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+def test_adapter_scores_a_pinned_host_set_in_place(tmp_path, orc):
+    """INTEGRATION Option 1 through the C++ adapter: the host-resident std::vector<PFSample> of the reference, pinned
+    once (PinnedSamples), handed to applyModelToSampleSet -- one scoring launch reads and writes the records in place."""
+    exe = _compile(tmp_path)
+    sc = Scenario(orc, size=200, n=20000, beams=91, cloud="mixture")
+    paths = {}
+    for name, arr in (("cells", sc.cells.astype(np.int32)), ("lut", sc.lut.astype(np.float32)),
+                      ("samples", sc.samples), ("ranges", sc.ranges), ("angles", sc.angles)):
+        paths[name] = str(tmp_path / (name + ".bin"))
+        np.ascontiguousarray(arr).tofile(paths[name])
+    out_w, out_r, out_l, out_h = (str(tmp_path / f) for f in ("w.bin", "r.bin", "l.bin", "h.bin"))
+    res = subprocess.run([str(exe), paths["cells"], paths["lut"], paths["samples"], paths["ranges"], paths["angles"], "200",
+                          out_w, out_r, out_l, out_h], capture_output=True, text=True, check=True)
+    assert "chunks -1 pinned 1" in res.stderr, res.stderr
+    want = sc.samples.copy()
+    want_total = sc.oracle_apply(sc.oracle_planar(91, "lf"), want)
+    got = np.fromfile(out_h, dtype=np.float64).reshape(-1, 4)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert (rel_err(got[:, 3], want[:, 3]) > 1e-9).sum() <= 1
+    total = float(res.stderr.split("total")[1].split()[0])
+    assert abs(total - want_total) <= 1e-9 * abs(want_total)
