@@ -111,7 +111,7 @@ public:
     dirty_ = true;
   }
   // OccupancyMap::updateDistancesLUT (occupancy_map.cpp:138-252): the reference's own priority-queue brushfire, the
-  // reference's values bit for bit (host, once per map as in the reference, ~0.7 s per 2000^2 map)
+  // reference's values bit for bit (host, once per map as in the reference, ~0.45 s per 2000^2 map)
   void updateDistancesLUT(double max_distance_to_object)
   {
     upload();

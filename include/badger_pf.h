@@ -102,7 +102,7 @@ int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, cons
                          const double* max_range, int n, double* range_out);
 /* OccupancyMap::updateDistancesLUT exactly as the reference builds it (occupancy_map.cpp:138-252):
  * priority-queue brushfire on the host (std::priority_queue, so tie order matches a libstdc++
- * build of the reference), ~0.7 s for a 2000 x 2000 map, once per map as in the reference.  THE DEFAULT behind the
+ * build of the reference), ~0.45 s for a 2000 x 2000 map, once per map as in the reference.  THE DEFAULT behind the
  * reference-named calls. */
 int bpf_map2d_build_distances_lut_reference(bpf_engine* e, double max_dist);
 
