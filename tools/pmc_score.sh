@@ -26,7 +26,9 @@ for f in glob.glob(out + "/p*/p_counter_collection.csv"):
         if "k_score" in k or "k_cloud_score" in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fh:
-    for k, d in agg.items():
+    # the kernel with the most dispatches first (pmc_json.py reads the first): a spread cloud's first update still
+    # runs the index-order form, the host-buffer path has forms of its own
+    for k, d in sorted(agg.items(), key=lambda kv: -max(len(v) for v in kv[1].values())):
         print(k, file=fh); print(k)
         for c, v in sorted(d.items()):
             line = "  %-34s n=%d mean=%.5g" % (c, len(v), sum(v) / len(v))
