@@ -28,7 +28,7 @@ int host_reg_add(bpf_engine* e, void* ptr, size_t bytes, bool automatic)
     auto& r = e->host_regs[i];
     if (a < r.base + r.bytes && r.base < a + bytes)
     {
-      if (!(automatic && r.automatic))
+      if (!r.automatic)  // an owner's registration is never dropped behind the owner's back
         return e->fail(BPF_ERR_INVALID_ARGUMENT, "host buffer overlaps a registered range");
       (void)hipHostUnregister(reinterpret_cast<void*>(r.base));
       e->host_regs.erase(e->host_regs.begin() + (long)i);
