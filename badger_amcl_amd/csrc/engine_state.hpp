@@ -410,6 +410,8 @@ struct bpf_engine
   bool last_seam_registered = false;
   bool tree_pending = false;        // the current set's histogram tree (leaf / bin counts) has not been built yet
 
+  std::vector<double> stage_bx, stage_by;  // stage_field_scan's scratch: beam end points of every decimated beam
+
   // ---- tile-sorted scoring of a spread cloud (kernels_window.hpp, HOST_MODE 3 of k_score_field)
   bool tile_sort = true;            // BPF_OPT_TILE_SORT
   bool spread_init = false;         // the set was initialised with uniform random poses and not resampled since

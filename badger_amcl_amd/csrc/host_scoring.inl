@@ -53,13 +53,47 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
       e->trig_sin[i] = std::sin(angles[i]);
     }
   }
-  std::vector<double2> beams;
-  beams.reserve(rc / step + 1);
+  // This runs between the launch that wrote the poses and the prep launch, with the GPU waiting (9 us for 1081 beams as
+  // one loop with its tests and push_backs): the products and the two divisions per beam first, for every decimated
+  // beam and without a branch (the compiler vectorises it), then the tests, writing the kept beams straight into the
+  // pinned slot: 4.7 us.  Same expressions, same bits.
+  const int m_beams = (rc + step - 1) / step;
+  if ((int)e->stage_bx.size() < m_beams)
+  {
+    e->stage_bx.resize(m_beams);
+    e->stage_by.resize(m_beams);
+  }
+  const double res = e->map.resolution;
+  {
+    double* bx = e->stage_bx.data();
+    double* by = e->stage_by.data();
+    const double* tc = e->trig_cos.data();
+    const double* ts = e->trig_sin.data();
+    if (step == 1)
+      for (int i = 0; i < rc; ++i)
+      {
+        bx[i] = (ranges[i] * tc[i]) / res;
+        by[i] = (ranges[i] * ts[i]) / res;
+      }
+    else
+      for (int k = 0, i = 0; i < rc; i += step, ++k)
+      {
+        bx[k] = (ranges[i] * tc[i]) / res;
+        by[k] = (ranges[i] * ts[i]) / res;
+      }
+  }
+  fs->beams_off = 0;
+  ScanSlot* s;
+  int rcode = acquire_slot(e, (((size_t)m_beams * sizeof(double2) + 255) & ~(size_t)255) +
+                                  (size_t)fs->table_len * sizeof(double), &s);  // room for every decimated beam
+  if (rcode != BPF_OK)
+    return rcode;
+  double2* out = reinterpret_cast<double2*>(s->host.p + fs->beams_off);
   fs->slot_of.clear();
+  fs->slot_of.reserve((size_t)m_beams);
   fs->n_valid = 0;
   fs->n_always_off = 0;
-  int slot = 0;
-  const double res = e->map.resolution;
+  int slot = 0, n_out = 0;
   for (int i = 0; i < rc; i += step, ++slot)
   {
     const double r = ranges[i];
@@ -70,32 +104,32 @@ int stage_field_scan(bpf_engine* e, const double* ranges, const double* angles, 
     ++fs->n_valid;
     if (keep_slot && !(slot < (int)keep_slot->size() && (*keep_slot)[slot]))
       continue;
-    double2 b;
-    b.x = (r * e->trig_cos[i]) / res;
-    b.y = (r * e->trig_sin[i]) / res;
+    const double b_x = e->stage_bx[slot], b_y = e->stage_by[slot];
     // a non-finite or absurdly long beam (> 2^28 cells) ends off the map for every pose in the
     // reference ((int) of a NaN or huge double is INT_MIN on x86): it is not staged, its constant
     // off-map term is added in the epilogue instead
-    if (!(std::fabs(b.x) < 268435456.0 && std::fabs(b.y) < 268435456.0))
+    if (!(std::fabs(b_x) < 268435456.0 && std::fabs(b_y) < 268435456.0))
     {
       ++fs->n_always_off;
       continue;
     }
-    beams.push_back(b);
+    if (n_out < kMaxBeams)
+    {
+      out[n_out].x = b_x;
+      out[n_out].y = b_y;
+    }
+    ++n_out;
     fs->slot_of.push_back(slot);
   }
   fs->n_slots = slot;
-  fs->n_staged = (int)beams.size();
+  fs->n_staged = n_out;
   if (fs->n_staged > kMaxBeams)
+  {
+    (void)release_slot(e, s);
     return e->fail(BPF_ERR_CAPACITY, "more than 4096 beams per scan after decimation");
-  fs->beams_off = 0;
+  }
   fs->table_off = ((size_t)fs->n_staged * sizeof(double2) + 255) & ~(size_t)255;
   fs->bytes = fs->table_off + (size_t)fs->table_len * sizeof(double);
-  ScanSlot* s;
-  int rcode = acquire_slot(e, fs->bytes, &s);
-  if (rcode != BPF_OK)
-    return rcode;
-  std::memcpy(s->host.p + fs->beams_off, beams.data(), beams.size() * sizeof(double2));
   double* table = reinterpret_cast<double*>(s->host.p + fs->table_off);
   bpf_engine::TermKey key;
   key.model = pm.model;
