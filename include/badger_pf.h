@@ -177,7 +177,10 @@ int bpf_pf_set_rng_state(bpf_engine* e, uint64_t state48);
 int bpf_pf_get_rng_state(const bpf_engine* e, uint64_t* state48);
 /* Load the current set (what initWithPoseFn/initWithGaussian leave behind, :106-162):
  * resets w_slow/w_fast and converged.  leaf_count = that set's kd-tree leaf count, or -1
- * to have it computed from the poses. */
+ * to have it computed from the poses -- when something first needs it (bpf_pf_get_state, the systematic resampler,
+ * a snapshot) or before the poses move (a motion update): the tree is that of the poses handed over here, as in the
+ * reference, but a cycle that uploads, updates and resamples with the multinomial resampler never builds it.
+ * A registered `samples` buffer (bpf_host_buffer_register) is read by the copy engine directly. */
 int bpf_pf_set_samples(bpf_engine* e, const double* samples, int sample_count, int leaf_count);
 int bpf_pf_get_samples(bpf_engine* e, double* samples_out, int capacity, int* sample_count_out);
 /* Keep a device-resident copy of the current set (poses, weights, counts) and put it back
