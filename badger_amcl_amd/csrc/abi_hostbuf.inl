@@ -1,9 +1,11 @@
 // C-ABI: caller-owned host buffers (the reference keeps its particles in a host std::vector<PFSample> that is
 // allocated once, particle_filter.cpp:62-89, and hands it to the sensor model every cycle).
 // ---------------------------------------------------------------------- host buffers
-// A pageable buffer crosses PCIe through the runtime's bounce buffers at ~13 GB/s with the calling thread doing the
-// staging copy; a buffer pinned with hipHostRegister is read by the copy engine directly (~50 GB/s, no host work).
-// Registration costs about a millisecond, so it is done ONCE per buffer and kept.  It is the OWNER's statement that
+// A pageable buffer crosses PCIe through the runtime's pinning / bounce path: 3.2 MB go up at the link's rate too
+// (64 us, tools/ubench/pcie_probe.hip), but the calling thread is busy inside the call for that long and a download
+// into it takes 44 us per 0.8 MB instead of 22; a buffer pinned with hipHostRegister is read and written by the copy
+// engine -- or by a kernel -- directly, with the calling thread free.  Registration costs 60 us to a millisecond, so
+// it is done ONCE per buffer and kept.  It is the OWNER's statement that
 // the memory stays allocated until bpf_host_buffer_unregister / bpf_destroy: the driver follows a registered range
 // by virtual address, and a range that has been freed (or freed and re-allocated) under a live registration makes
 // the next DMA fault.  That is why the engine does not cache registrations by pointer on its own

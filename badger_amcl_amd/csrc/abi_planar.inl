@@ -284,7 +284,12 @@ int apply_model_pipelined(bpf_engine* e, double* samples, int n, int set_converg
                             e->h_seam_flags.p + c, gen };
     rcode = launch_field(e, p, cnt, s, fc, nullptr, 0, false, direct ? dev_view + lo : e->d_aos.p + lo, &out);
     if (rcode != BPF_OK)
+    {
+      // the copy engine and the launches already issued read the caller's buffer: let them finish before returning
+      (void)hipStreamSynchronize(e->copy_up);
+      (void)hipStreamSynchronize(e->stream);
       return rcode;
+    }
   }
   rcode = release_slot(e, s);
   if (rcode != BPF_OK)
@@ -366,14 +371,19 @@ double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int 
   HIPCHK_OR(e, e->scratch.reserve((size_t)sample_count), bail);
   HIPCHK_OR(e, hipMemcpyAsync(e->d_aos.p, samples, (size_t)sample_count * sizeof(double4), hipMemcpyHostToDevice,
                               e->stream), bail);
+  // from here on the copy engine may still be reading the caller's (registered) buffer: no return before it is done
+  auto bail_sync = [&](int code) {
+    (void)hipStreamSynchronize(e->stream);
+    return bail(code);
+  };
   bool forced_zero = false;
   rc = score_planar(e, e->scratch.dev(), sample_count, set_converged, ranges, angles, range_count, range_max,
                     &forced_zero, false, false, e->d_aos.p);
   if (rc != BPF_OK)
-    return bail(rc);
+    return bail_sync(rc);
   rc = sum_into_slot(e, e->scratch.w.p, sample_count, 0, 0, sample_count);
   if (rc != BPF_OK)
-    return bail(rc);
+    return bail_sync(rc);
   rc = download_weights(e, e->scratch, sample_count, samples);
   if (rc != BPF_OK)
     return bail(rc);
