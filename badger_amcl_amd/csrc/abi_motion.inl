@@ -258,6 +258,7 @@ int bpf_pf_init_with_gaussian(bpf_engine* e, const double mean[3], const double 
   if (rc != BPF_OK)
     return rc;
   e->rng = lcg_skip_host(e->rng, (uint64_t)consumed, e->jump);
+  e->spread_init = false;
   return finish_init(e, n);
 }
 
