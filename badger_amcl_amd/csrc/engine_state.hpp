@@ -348,6 +348,7 @@ struct bpf_engine
   // the tree in LDS-sized pieces (kernels_kld2.hpp)
   DevBuf<int> d_kld2_int;       // tkeys[n] bucket[n] bk[n] cnt[N] off[N + 1] fill[N] n_tkeys n_top status[2]
   DevBuf<Kld2Top> d_kld2_top;
+  DevBuf<unsigned long long> d_kld2_slots;  // look-back slots of k_kld2_scan
   bool kld_local = true;        // BPF_OPT_KLD_LOCAL
   bool kld2_attr_set = false;
   int kld_last_form = 0;        // diagnostics: 2 = LDS pieces, 1 = level loop, 3 = persistent
@@ -415,7 +416,8 @@ struct bpf_engine
   // ---- tile-sorted scoring of a spread cloud (kernels_window.hpp, HOST_MODE 3 of k_score_field)
   bool tile_sort = true;            // BPF_OPT_TILE_SORT
   bool spread_init = false;         // the set was initialised with uniform random poses and not resampled since
-  DevBuf<int> d_tile_int;           // hist[kTileBins] cursor[kTileBins] tile[n] perm[n]
+  DevBuf<int> d_tile_int;           // hist[2][kTileBins] cursor[kTileBins] tile[n] perm[n]
+  int tile_parity = 0;              // which half of hist the last tile-sorted update counted into
   DevBuf<double4> d_prep_sorted;
   int last_score_form = 0;          // diagnostics: 3 = the last scoring launch walked the particles in tile order
 

@@ -447,8 +447,9 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   K.flags = e->d_kld_flags.p;
   K.limit = e->d_kld_limit.p;
   const dim3 grid(blocks_for(n, 256)), block(256);
+  const bool local = e->kld_local && allow_local && !e->kld_persistent;
   hipLaunchKernelGGL(k_kld_clear, dim3(std::min(1024, blocks_for((int)std::max<unsigned>(table, 2u * (unsigned)n), 256))),
-                     block, 0, e->stream, K, table, 4 + kMaxLevels);
+                     block, 0, e->stream, K, table, 4 + kMaxLevels, local ? 0 : 1);
   hipLaunchKernelGGL(k_kld_hash, grid, block, 0, e->stream, K);
   if (e->kld_persistent)
   {
@@ -520,7 +521,6 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
       return kld_tree_on_device(e, maxs, handled, stop_out, leaf_out, bins_out, whole_stream);
     }
   }
-  const bool local = e->kld_local && allow_local;
   e->kld_last_form = local ? 2 : 1;
   if (local)
   {
@@ -569,11 +569,14 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
     hipLaunchKernelGGL(k_kld2_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, L);
     hipLaunchKernelGGL(k_kld2_subtrees, dim3(blocks_for(n, kKld2Span) + 1), dim3(kKld2Block), kKld2LdsBytes, e->stream,
                        L);
-    hipLaunchKernelGGL(k_kld_scan_tiles, dim3(tiles), dim3(256), 0, e->stream, (const int2*)e->d_kld_delta.p, n,
-                       e->d_kld_tiles.p);
-    hipLaunchKernelGGL(k_kld_scan_offsets, dim3(1), dim3(1024), 0, e->stream, e->d_kld_tiles.p, tiles);
-    hipLaunchKernelGGL(k_kld_scan_final, dim3(tiles), dim3(256), 0, e->stream, K, (const int2*)e->d_kld_tiles.p,
-                       e->d_kld_counts.p);
+    // prefix sums + stop test in one launch (look-back slots tagged with the generation: reserved and zeroed once)
+    if (e->d_kld2_slots.cap < (size_t)tiles)
+    {
+      HIPCHK(e, e->d_kld2_slots.reserve((size_t)std::max(tiles, 1024)));
+      HIPCHK(e, hipMemsetAsync(e->d_kld2_slots.p, 0, e->d_kld2_slots.cap * sizeof(unsigned long long), e->stream));
+    }
+    hipLaunchKernelGGL(k_kld2_scan, dim3(tiles), dim3(256), 0, e->stream, K, e->d_kld2_slots.p,
+                       (unsigned)L.generation, e->d_kld_counts.p, L.status);
     hipLaunchKernelGGL(k_kld2_result, dim3(1), dim3(64), 0, e->stream, L);
     HIPCHK(e, hipGetLastError());
     // the result block in pinned memory, its generation word last: one poll instead of three copies with a

@@ -276,20 +276,22 @@ int launch_field(bpf_engine* e, ParticlesDev p, int n, ScanSlot* s, const FieldS
       while ((((e->map.size_x + 2) >> shift) + 1) > 64 || (((e->map.size_y + 2) >> shift) + 1) > 64)
         ++shift;
       const int txc = ((e->map.size_x + 2) >> shift) + 1, tyc = ((e->map.size_y + 2) >> shift) + 1;
-      const bool fresh = e->d_tile_int.cap < (size_t)2 * kTileBins + 2 * (size_t)n;
-      HIPCHK(e, e->d_tile_int.reserve((size_t)2 * kTileBins + 2 * (size_t)n));
+      const bool fresh = e->d_tile_int.cap < (size_t)3 * kTileBins + 2 * (size_t)n;
+      HIPCHK(e, e->d_tile_int.reserve((size_t)3 * kTileBins + 2 * (size_t)n));
       HIPCHK(e, e->d_prep_sorted.reserve((size_t)n));
-      int* hist = e->d_tile_int.p;
-      int* cursor = hist + kTileBins;
+      if (fresh)  // both halves of the histogram start at zero; from then on each update zeroes the other half
+        HIPCHK(e, hipMemsetAsync(e->d_tile_int.p, 0, 3 * kTileBins * sizeof(int), e->stream));
+      e->tile_parity ^= 1;
+      int* hist = e->d_tile_int.p + (size_t)e->tile_parity * kTileBins;
+      int* hist_next = e->d_tile_int.p + (size_t)(e->tile_parity ^ 1) * kTileBins;
+      int* cursor = e->d_tile_int.p + 2 * kTileBins;
       int* tile = cursor + kTileBins;
       int* perm = tile + n;
-      if (fresh)  // the offsets launch leaves the counts at zero for the next scan
-        HIPCHK(e, hipMemsetAsync(hist, 0, kTileBins * sizeof(int), e->stream));
       hipLaunchKernelGGL(k_field_prep_tile, dim3(prep_blocks), dim3(256), 0, e->stream, p, n, e->map, A.sp_x, A.sp_y,
-                         A.sp_th, e->d_prep.p, tile, hist, shift, txc, tyc, src, reinterpret_cast<uint4*>(s->dev.p), n16);
-      hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, e->stream, hist, cursor);
-      hipLaunchKernelGGL(k_tile_scatter, dim3(prep_blocks), dim3(256), 0, e->stream, n, (const int*)tile, cursor,
-                         (const double4*)e->d_prep.p, perm, e->d_prep_sorted.p);
+                         A.sp_th, e->d_prep.p, tile, hist, hist_next, cursor, shift, txc, tyc, src,
+                         reinterpret_cast<uint4*>(s->dev.p), n16);
+      hipLaunchKernelGGL(k_tile_scatter, dim3(prep_blocks), dim3(256), 0, e->stream, n, (const int*)tile,
+                         (const int*)hist, cursor, (const double4*)e->d_prep.p, perm, e->d_prep_sorted.p);
       A.perm = perm;
     }
     else if (aos != nullptr)

@@ -94,7 +94,8 @@ __device__ __forceinline__ void block_atomic_min(int* base, unsigned a, int i, b
 
 // the tree's tables in their start state, one launch instead of six memsets (~4.4 us each): hash keys all-ones, the
 // int tables 0x7F7F7F7F ("later than any draw"), the flag words zero except the stop index
-__global__ void k_kld_clear(const KldArgs A, unsigned table, int n_flags)
+// tree_tables = 0: the tree is grown in LDS-sized pieces (kernels_kld2.hpp), first[] / child[] are not used
+__global__ void k_kld_clear(const KldArgs A, unsigned table, int n_flags, int tree_tables = 1)
 {
   const unsigned stride = gridDim.x * blockDim.x;
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,9 +104,9 @@ __global__ void k_kld_clear(const KldArgs A, unsigned table, int n_flags)
     A.h_key[i] = kKldEmpty;
     A.h_tmin[i] = 0x7F7F7F7F;
   }
-  for (unsigned i = t; i < (unsigned)A.n; i += stride)
+  for (unsigned i = t; tree_tables && i < (unsigned)A.n; i += stride)
     A.first[i] = 0x7F7F7F7F;
-  for (unsigned i = t; i < 2u * (unsigned)A.n; i += stride)
+  for (unsigned i = t; tree_tables && i < 2u * (unsigned)A.n; i += stride)
     A.child[i] = 0x7F7F7F7F;
   for (unsigned i = t; i < (unsigned)n_flags; i += stride)
     A.flags[i] = (i == 2u) ? 0x7F7F7F7F : 0;

@@ -449,6 +449,112 @@ __global__ __launch_bounds__(kKld2Block) void k_kld2_subtrees(const Kld2Args A)
     A.status[0] = BPF_KLD2_TOO_DEEP;
 }
 
+// The prefix sums over delta[] (leaf count and bin count after every draw) and the stop test in ONE launch instead
+// of three (tile sums, offsets, final): every block adds up its tile, publishes the pair behind the launch's
+// generation in one 64-bit word -- (generation << 40) | (leaves << 20) | bins, the value is its own flag, nothing to
+// reset -- and reads the tiles before it (blocks are dispatched in index order: they are resident or done; the wait
+// is bounded all the same).  Tiles of kKldTile draws as in k_kld_scan_final, same counts[] and the same stop word.
+__global__ __launch_bounds__(256) void k_kld2_scan(const KldArgs A, unsigned long long* __restrict__ slots,
+                                                  unsigned generation, int2* __restrict__ counts, int* status)
+{
+  __shared__ int2 s_w[4];
+  __shared__ int2 s_off;
+  constexpr int per = kKldTile / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int base = b * kKldTile + tid * per;
+  int2 v[per];
+  int2 sum = make_int2(0, 0);
+#pragma unroll
+  for (int j = 0; j < per; ++j)
+  {
+    v[j] = (base + j < A.n) ? A.delta[base + j] : make_int2(0, 0);
+    sum.x += v[j].x;
+    sum.y += v[j].y;
+  }
+  int2 incl = sum;
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int ux = __shfl_up(incl.x, o, 64), uy = __shfl_up(incl.y, o, 64);
+    if (lane >= o)
+    {
+      incl.x += ux;
+      incl.y += uy;
+    }
+  }
+  if (lane == 63)
+    s_w[wave] = incl;
+  __syncthreads();
+  const unsigned long long tag = (unsigned long long)(generation % 0xFFFFFFu + 1u) << 40;  // never the zeroed slot's
+  if (tid == 0)
+  {
+    const int tx = s_w[0].x + s_w[1].x + s_w[2].x + s_w[3].x, ty = s_w[0].y + s_w[1].y + s_w[2].y + s_w[3].y;
+    __hip_atomic_store(&slots[b], tag | ((unsigned long long)(unsigned)tx << 20) | (unsigned long long)(unsigned)ty,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // the tiles before this one: thread t fetches tile t (strided for more than 256 tiles), the waves add up
+  int2 before = make_int2(0, 0);
+  for (int t = tid; t < b; t += 256)
+  {
+    unsigned long long w;
+    long long t0 = 0;
+    for (unsigned spins = 0; ((w = __hip_atomic_load(&slots[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 40) !=
+                             (tag >> 40); ++spins)
+    {
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 255u) == 255u)
+      {
+        const long long now = wall_clock64();
+        if (t0 == 0)
+          t0 = now;
+        else if (now - t0 > 5000000ll)  // 50 ms: the tile counts as empty, the status word says so
+        {
+          atomicExch(status, BPF_KLD2_TOO_DEEP);
+          w = tag;
+          break;
+        }
+      }
+    }
+    before.x += (int)((w >> 20) & 0xFFFFFull);
+    before.y += (int)(w & 0xFFFFFull);
+  }
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    before.x += __shfl_xor(before.x, o, 64);
+    before.y += __shfl_xor(before.y, o, 64);
+  }
+  __shared__ int2 s_b[4];
+  if (lane == 0)
+    s_b[wave] = before;
+  __syncthreads();
+  if (tid == 0)
+    s_off = make_int2(s_b[0].x + s_b[1].x + s_b[2].x + s_b[3].x, s_b[0].y + s_b[1].y + s_b[2].y + s_b[3].y);
+  __syncthreads();
+  int2 run = s_off;
+  for (int q = 0; q < wave; ++q)
+  {
+    run.x += s_w[q].x;
+    run.y += s_w[q].y;
+  }
+  run.x += incl.x - sum.x;
+  run.y += incl.y - sum.y;
+  int stop = INT_MAX;
+#pragma unroll
+  for (int j = 0; j < per; ++j)
+  {
+    const int m = base + j;
+    if (m < A.n)
+    {
+      run.x += v[j].x;
+      run.y += v[j].y;
+      counts[m] = run;
+      if (m + 1 > A.limit[run.x] && stop == INT_MAX)
+        stop = m + 1;
+    }
+  }
+  if (stop != INT_MAX)
+    atomicMin(&A.flags[2], stop);
+}
+
 // what the host wants to know, in one pinned block behind a generation word: [1] key outside the packing, [2] stop
 // index (flags[2]), [3] leaf count and [4] bin count at the stop (or at n), [5] status, [6] tree keys, [7] largest bucket
 __global__ void k_kld2_result(const Kld2Args A)

@@ -150,15 +150,25 @@ __device__ __forceinline__ int wave_bin_add(int* counters, int bin, bool active)
   return active ? atomicAdd(&counters[bin], 1) : 0;
 }
 
+// `hist` is this update's half of a double-buffered histogram (zero on entry); block 0 puts the other half and the
+// cursors back to zero for the next update, so there is no clearing launch and no offsets launch (k_tile_scatter
+// forms the offsets itself).
 __global__ __launch_bounds__(256) void k_field_prep_tile(ParticlesDev p, int n, MapDev M, double ax, double ay, double ath,
                                                         double4* __restrict__ prep, int* __restrict__ tile,
-                                                        int* __restrict__ hist, int shift, int tx_count, int ty_count,
+                                                        int* __restrict__ hist, int* __restrict__ hist_next,
+                                                        int* __restrict__ cursor, int shift, int tx_count, int ty_count,
                                                         const uint4* __restrict__ stage_src,
                                                         uint4* __restrict__ stage_dst, int stage_n16)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (stage_src != nullptr && i < stage_n16)
     stage_dst[i] = stage_src[i];
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < kTileBins; k += 256)
+    {
+      hist_next[k] = 0;
+      cursor[k] = 0;
+    }
   int t = 0;
   if (i < n)
   {
@@ -171,48 +181,49 @@ __global__ __launch_bounds__(256) void k_field_prep_tile(ParticlesDev p, int n, 
   (void)wave_bin_add(hist, t, i < n);
 }
 
-// one block: exclusive prefix of the bin counts; the counts are left at zero for the next scan, the cursors at the
-// bins' offsets
-__global__ __launch_bounds__(1024) void k_tile_offsets(int* __restrict__ hist, int* __restrict__ cursor)
+// every block forms the bins' offsets itself (exclusive prefix of the 4096 counts in LDS: 16 KB of reads per block,
+// cheaper than a launch of its own), then places its particles: offset of the bin + the bin's cursor
+__global__ __launch_bounds__(256) void k_tile_scatter(int n, const int* __restrict__ tile, const int* __restrict__ hist,
+                                                     int* __restrict__ cursor, const double4* __restrict__ prep,
+                                                     int* __restrict__ perm, double4* __restrict__ prep_sorted)
 {
-  __shared__ int s_part[1024];
-  const int tid = threadIdx.x;
-  constexpr int per = kTileBins / 1024;
+  __shared__ int s_off[kTileBins];
+  __shared__ int s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int per = kTileBins / 256;
   int v[per], sum = 0;
 #pragma unroll
   for (int q = 0; q < per; ++q)
   {
     v[q] = hist[tid * per + q];
     sum += v[q];
-    hist[tid * per + q] = 0;
   }
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1)
+  int incl = sum;
+  for (int o = 1; o < 64; o <<= 1)
   {
-    const int u = tid >= o ? s_part[tid - o] : 0;
-    __syncthreads();
-    s_part[tid] += u;
-    __syncthreads();
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o)
+      incl += u;
   }
-  int run = s_part[tid] - sum;
+  if (lane == 63)
+    s_w[wave] = incl;
+  __syncthreads();
+  int run = incl - sum;
+  for (int q = 0; q < wave; ++q)
+    run += s_w[q];
 #pragma unroll
   for (int q = 0; q < per; ++q)
   {
-    cursor[tid * per + q] = run;
+    s_off[tid * per + q] = run;
     run += v[q];
   }
-}
-
-__global__ __launch_bounds__(256) void k_tile_scatter(int n, const int* __restrict__ tile, int* __restrict__ cursor,
-                                                     const double4* __restrict__ prep, int* __restrict__ perm,
-                                                     double4* __restrict__ prep_sorted)
-{
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __syncthreads();
+  const int i = blockIdx.x * 256 + tid;
   const int t = i < n ? tile[i] : 0;
-  const int pos = wave_bin_add(cursor, t, i < n);
+  const int rank = wave_bin_add(cursor, t, i < n);
   if (i < n)
   {
+    const int pos = s_off[t] + rank;
     perm[pos] = i;
     prep_sorted[pos] = prep[i];
   }
