@@ -185,76 +185,126 @@ __device__ __forceinline__ unsigned long long kld2_pair(int idx, int loc)
 // Grows the subtrees of all the keys in the table (entries [0, n_entries); keys are those with cur >= 0) level by
 // level in LDS: two block barriers per level.  delta[]: a key that is the first one routed through its parent gets
 // leaf-count delta 0.  Returns false when it does not finish within kKld2MaxIter levels.
-__device__ __forceinline__ bool kld2_grow(const Kld2Lds& L, int n_entries, int2* __restrict__ delta)
+// A thread's own keys (key, draw index, current node) live in registers for the whole build, and a level's LDS reads
+// are issued for all of a thread's keys before anything depends on them: a level is then three dependent LDS round
+// trips (node record, first key's key, the minimum) + two (the child, the report) instead of twice as many.
+// __syncthreads() also waits for the block's outstanding GLOBAL stores; the levels only exchange through LDS.
+__device__ __forceinline__ void kld2_lds_barrier()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// s_more: three words of LDS, zero on entry (the levels' "anyone still waiting" flags, used in rotation: a level's
+// flag is cleared two levels before it is set and read one barrier after).
+__device__ __forceinline__ bool kld2_grow(const Kld2Lds& L, int n_entries, int2* __restrict__ delta, int* s_more)
 {
   constexpr int kPer = kKld2Nodes / kKld2Block;
   const int tid = threadIdx.x;
-  // a key that arrives at a node whose axis is unknown reports to it (the earliest becomes the node's first key)
+  unsigned long long kj[kPer];
+  int ij[kPer], cj[kPer];
 #pragma unroll
   for (int q = 0; q < kPer; ++q)
   {
     const int j = tid + q * kKld2Block;
-    if (j < n_entries && L.cur[j] >= 0 && L.axis[L.cur[j]] < 0)
-      atomicMin(&L.first[L.cur[j]], kld2_pair(L.idx[j], j));
+    const bool in = j < n_entries;
+    kj[q] = in ? L.key[j] : 0ull;
+    ij[q] = in ? L.idx[j] : 0;
+    cj[q] = in ? L.cur[j] : -1;
+    // a key that arrives at a node whose axis is unknown reports to it (the earliest becomes the node's first key)
+    if (cj[q] >= 0 && L.axis[cj[q]] < 0)
+      atomicMin(&L.first[cj[q]], kld2_pair(ij[q], j));
   }
-  __syncthreads();
-  for (int iter = 0; iter < kKld2MaxIter; ++iter)
+  bool is_first[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q)
+    is_first[q] = false;
+  bool done = false;
+  kld2_lds_barrier();
+  for (int iter = 0, r = 0; iter < kKld2MaxIter; ++iter, r = r == 2 ? 0 : r + 1)
   {
-    // the node's axis from its first key (every waiting key works it out for itself; the first key records it, and
-    // its creation ends the node's time as a leaf), then the earliest waiting key on each side of the node
-    int slot[kPer];
+    // the node's axis from its first key (every waiting key works it out for itself; the first key's creation ends
+    // the node's time as a leaf), then the earliest waiting key on each side of the node
+    int slot[kPer], ax[kPer], fl[kPer];
+    unsigned long long kc[kPer];
 #pragma unroll
     for (int q = 0; q < kPer; ++q)
     {
-      const int j = tid + q * kKld2Block;
-      slot[q] = -1;
-      if (j < n_entries && L.cur[j] >= 0)
+      ax[q] = 0;
+      fl[q] = 0;
+      kc[q] = 0ull;
+      if (cj[q] >= 0)
       {
-        const int c = L.cur[j];
-        int ax = L.axis[c];
-        if (ax < 0)
-        {
-          const int f = (int)(unsigned)(L.first[c] & 0xFFFFFFFFull);
-          ax = kld2_axis(L.key[c], L.key[f]);
-          if (f == j)
-            delta[L.idx[j]].x = 0;
-        }
-        slot[q] = 2 * c + (kld2_field(L.key[j], ax) > kld2_field(L.key[c], ax) ? 1 : 0);
-        atomicMin(&L.child[slot[q]], kld2_pair(L.idx[j], j));
+        ax[q] = L.axis[cj[q]];
+        fl[q] = (int)(unsigned)(L.first[cj[q]] & 0xFFFFFFFFull);
+        kc[q] = L.key[cj[q]];
       }
     }
-    __syncthreads();
-    // that key is the child node now; the others step down to it and report to it
-    int still = 0;
 #pragma unroll
     for (int q = 0; q < kPer; ++q)
     {
-      const int j = tid + q * kKld2Block;
+      slot[q] = -1;
+      if (cj[q] >= 0)
+      {
+        const int j = tid + q * kKld2Block;
+        if (ax[q] < 0)
+        {
+          ax[q] = kld2_axis(kc[q], L.key[fl[q]]);
+          is_first[q] = is_first[q] || fl[q] == j;
+        }
+        slot[q] = 2 * cj[q] + (kld2_field(kj[q], ax[q]) > kld2_field(kc[q], ax[q]) ? 1 : 0);
+        atomicMin(&L.child[slot[q]], kld2_pair(ij[q], j));
+      }
+    }
+    kld2_lds_barrier();
+    // that key is the child node now; the others step down to it and report to it
+    int still = 0;
+    int ch[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q)
+      ch[q] = slot[q] >= 0 ? (int)(unsigned)(L.child[slot[q]] & 0xFFFFFFFFull) : -1;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q)
       if (slot[q] >= 0)
       {
-        const int c = (int)(unsigned)(L.child[slot[q]] & 0xFFFFFFFFull);
-        if (c == j)
-          L.cur[j] = -1;
+        const int j = tid + q * kKld2Block;
+        if (ch[q] == j)
+          cj[q] = -1;
         else
         {
-          L.cur[j] = c;
-          atomicMin(&L.first[c], kld2_pair(L.idx[j], j));
+          cj[q] = ch[q];
+          atomicMin(&L.first[ch[q]], kld2_pair(ij[q], j));
           still = 1;
         }
       }
+    if (tid == 0)
+      s_more[r == 2 ? 0 : r + 1] = 0;
+    if (__any(still) && (tid & 63) == 0)
+      s_more[r] = 1;
+    kld2_lds_barrier();
+    if (s_more[r] == 0)
+    {
+      done = true;
+      break;
     }
-    if (__syncthreads_count(still) == 0)
-      return true;
   }
-  return false;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q)
+    if (is_first[q])
+      delta[ij[q]].x = 0;
+  return done;
 }
 
 // phase A: T0 from the first n_top tree keys (all of them when the stream has at most kKld2Nodes), one block
 __global__ __launch_bounds__(kKld2Block) void k_kld2_top(const Kld2Args A)
 {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int s_more[3];
   const Kld2Lds L = kld2_lds(smem);
   const int tid = threadIdx.x;
+  if (tid < 3)
+    s_more[tid] = 0;
   const int n_t = *A.n_tkeys;
   const int n_top = n_t <= kKld2Nodes ? n_t : kKld2Top;
   for (int j = tid; j < n_top; j += kKld2Block)
@@ -268,7 +318,7 @@ __global__ __launch_bounds__(kKld2Block) void k_kld2_top(const Kld2Args A)
     L.child[2 * j + 1] = kKld2None;
   }
   __syncthreads();
-  const bool ok = n_top <= 1 || kld2_grow(L, n_top, A.K.delta);
+  const bool ok = n_top <= 1 || kld2_grow(L, n_top, A.K.delta, s_more);
   if (!ok && tid == 0)
     A.status[0] = BPF_KLD2_TOO_DEEP;
   for (int j = tid; j < n_top; j += kKld2Block)
@@ -387,9 +437,12 @@ __global__ __launch_bounds__(kKld2Block) void k_kld2_subtrees(const Kld2Args A)
 {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_range[2];
+  __shared__ int s_more[3];
   const int tid = threadIdx.x;
   if (A.status[0] != BPF_KLD2_OK)
     return;
+  if (tid >= 64 && tid < 67)
+    s_more[tid - 64] = 0;
   const int n_t = *A.n_tkeys, n_top = *A.n_top, total = n_t - n_top;
   const int w_lo = blockIdx.x * kKld2Span, w_hi = w_lo + kKld2Span;
   if (total <= 0 || w_lo >= total)
@@ -445,7 +498,7 @@ __global__ __launch_bounds__(kKld2Block) void k_kld2_subtrees(const Kld2Args A)
     }
   }
   __syncthreads();
-  if (!kld2_grow(L, nk, A.K.delta) && tid == 0)
+  if (!kld2_grow(L, nk, A.K.delta, s_more) && tid == 0)
     A.status[0] = BPF_KLD2_TOO_DEEP;
 }
 
