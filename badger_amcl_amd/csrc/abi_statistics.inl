@@ -89,6 +89,7 @@ int compute_cluster_stats_device(bpf_engine* e, bool* handled)
   HIPCHK(e, e->d_stats_result.reserve(1));
   HIPCHK(e, e->h_stats_result.reserve(1));
   HIPCHK(e, e->h_stats_flags.reserve(4));
+  e->kld_clean_table = 0;  // (the resampler's tables: in use here)
   HIPCHK(e, hipMemsetAsync(e->d_kld_hkey.p, 0xFF, (size_t)table * sizeof(unsigned long long), e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_kld_htmin.p, 0x7F, (size_t)table * sizeof(int), e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats_flags.p, 0, 4 * sizeof(int), e->stream));

@@ -351,6 +351,12 @@ struct bpf_engine
   DevBuf<unsigned long long> d_kld2_slots;  // look-back slots of k_kld2_scan
   bool kld_local = true;        // BPF_OPT_KLD_LOCAL
   bool kld2_attr_set = false;
+  // the histogram tree's hash tables were left in their start state behind the last build (pieces form): table size,
+  // buffers and capacities they were cleared at (0: not clean)
+  unsigned kld_clean_table = 0;
+  const void* kld_clean_key = nullptr;
+  const void* kld_clean_tmin = nullptr;
+  size_t kld_clean_cap = 0;
   int kld_last_form = 0;        // diagnostics: 2 = LDS pieces, 1 = level loop, 3 = persistent
   PinnedBuf<int> h_kld;
   std::vector<int> kld_limit_host;

@@ -448,8 +448,13 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   K.limit = e->d_kld_limit.p;
   const dim3 grid(blocks_for(n, 256)), block(256);
   const bool local = e->kld_local && allow_local && !e->kld_persistent;
-  hipLaunchKernelGGL(k_kld_clear, dim3(std::min(1024, blocks_for((int)std::max<unsigned>(table, 2u * (unsigned)n), 256))),
-                     block, 0, e->stream, K, table, 4 + kMaxLevels, local ? 0 : 1);
+  // (pieces form: the previous build cleared the tables behind its result, while the host was turning around)
+  const bool clean = local && e->kld_clean_table == table && e->kld_clean_key == e->d_kld_hkey.p &&
+                     e->kld_clean_tmin == e->d_kld_htmin.p && e->kld_clean_cap == e->d_kld_hkey.cap;
+  e->kld_clean_table = 0;
+  const dim3 clear_grid(std::min(1024, blocks_for((int)std::max<unsigned>(table, 2u * (unsigned)n), 256)));
+  if (!clean)
+    hipLaunchKernelGGL(k_kld_clear, clear_grid, block, 0, e->stream, K, table, 4 + kMaxLevels, local ? 0 : 1);
   hipLaunchKernelGGL(k_kld_hash, grid, block, 0, e->stream, K);
   if (e->kld_persistent)
   {
@@ -578,6 +583,9 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
     hipLaunchKernelGGL(k_kld2_scan, dim3(tiles), dim3(256), 0, e->stream, K, e->d_kld2_slots.p,
                        (unsigned)L.generation, e->d_kld_counts.p, L.status);
     hipLaunchKernelGGL(k_kld2_result, dim3(1), dim3(64), 0, e->stream, L);
+    // the next build's start state now, behind the result: the GPU does it while this thread turns around
+    hipLaunchKernelGGL(k_kld_clear, dim3(std::min(1024, blocks_for((int)table, 256))), block, 0, e->stream, K, table,
+                       4 + kMaxLevels, 0);
     HIPCHK(e, hipGetLastError());
     // the result block in pinned memory, its generation word last: one poll instead of three copies with a
     // stream synchronisation each
@@ -602,6 +610,10 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
     if (getenv("BPF_DEBUG"))
       fprintf(stderr, "[kld pieces] n %d tree keys %d status %d largest bucket %d stop %d leaf %d bins %d\n", n, res[6],
               res[5], res[7], res[2], res[3], res[4]);
+    e->kld_clean_table = table;
+    e->kld_clean_key = e->d_kld_hkey.p;
+    e->kld_clean_tmin = e->d_kld_htmin.p;
+    e->kld_clean_cap = e->d_kld_hkey.cap;
     if (res[1] != 0)
       return BPF_OK;  // a key outside the packing range: not handled
     if (res[5] != BPF_KLD2_OK)  // a bucket that does not fit a block, or a piece deeper than its budget
