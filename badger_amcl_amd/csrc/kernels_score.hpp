@@ -210,7 +210,7 @@ __device__ unsigned long long g_phase_cycles[kPhaseWaves][8];
 // HOST_MODE 3 has nothing to do with the host: TILE-SORTED scoring of a spread cloud.  With the particles all over the
 // map every XCD's 4 MB L2 sees the whole LUT (8.3 MB for a 2000 x 2000 map): 747 MB of L2 fills per launch against
 // 436 MB algorithmic, 6.3 TB/s, and the kernel waits for LUT lines (120 us where the converged cloud takes 73).  The
-// prep launch therefore also bins the particles by map tile (k_field_prep_tile, k_tile_offsets, k_tile_scatter: a
+// prep launch therefore also bins the particles by map tile (k_field_prep_tile, k_tile_scatter: a
 // counting sort into A.perm, prep values written in that order), this kernel walks slots in tile order and the
 // graded partition hands each XCD -- blocks b and b + 8 share one -- a CONTIGUOUS eighth of the slots (A.xcd_local),
 // i.e. an eighth of the map: its L2 then holds what its waves gather from.  85 us.  The order of the slots changes
