@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gc
 import bench
 class A: pass
-args = A(); args.map_size=2000; args.beams=1081; args.particles=100000; args.cloud="converged"; args.model="lf"; args.resampler="multinomial"; args.lut="exact-edt"
+args = A(); args.map_size=2000; args.beams=1081; args.particles=100000
+if len(sys.argv) > 3:  # particles beams map_size (configs[0]: 5000 181 400)
+    args.particles, args.beams, args.map_size = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+args.cloud="converged"; args.model="lf"; args.resampler="multinomial"; args.lut="exact-edt"
 wl = bench.build_workload(args, 0); wl["world"]=1
 e, m, sc, pf, data, lut = bench.setup_engine(args, wl, 0)
 for _ in range(10):
