@@ -21,7 +21,7 @@ class A:
 
 
 args = A(); args.map_size = 2000; args.beams = int(os.environ.get("BEAMS", 1081)); args.particles = 100000
-args.cloud = "converged"; args.model = "lf"; args.resampler = "multinomial"
+args.cloud = "converged"; args.model = "lf"; args.resampler = "multinomial"; args.lut = "exact-edt"
 wl = bench.build_workload(args, 0); wl["world"] = 1
 e, m, sc, pf, data, lut = bench.setup_engine(args, wl, 0)
 e.set_option(hpf.OPT_GRADED_SHARES, int(os.environ.get("GRADED", "1")))
@@ -52,3 +52,11 @@ tot = ph[live].sum()
 for k, nm in enumerate(names):
     print("%-26s %9.0f core cycles per wave  %5.1f %%" % (nm, ph[live, k].mean(), 100.0 * ph[live, k].sum() / tot))
 print("core clock %.0f MHz" % (ph[live].sum(axis=1).mean() / life[live].mean()))
+# end times per placement round and per XCD (blocks b and b + 8 share one): what finer grading could still level
+end = (t1 - t0[live].min()) / 100.0
+for r in range(4):
+    sel = live & (blk // 256 == r)
+    if sel.any():
+        print("round %d ends: p10 %.1f p50 %.1f p90 %.1f max %.1f" % (r, *[np.percentile(end[sel], q) for q in (10, 50, 90)], end[sel].max()))
+print("ends by XCD:", " ".join("%d:%.1f/%.1f" % (x, np.median(end[live & (blk % 8 == x)]), end[live & (blk % 8 == x)].max()) for x in range(8)))
+print("start by round:", " ".join("%d:%.1f" % (r, np.median((t0[live & (blk // 256 == r)] - t0[live].min()) / 100.0)) for r in range(4)))
