@@ -404,3 +404,26 @@ def test_histogram_tree_in_lds_pieces_equals_the_level_loop_and_the_oracle(engin
     assert got[1][:2] == got[0][:2] and got[1][0] == want_leaf
     assert got[0][2] == 1
     assert got[1][2] == (1 if kind == "line_then_blob" else 2)
+
+
+def test_histogram_tree_tables_shared_with_cluster_statistics_are_clean_again(engine, orc):
+    """The pieces form leaves the hash tables cleared BEHIND its result for the next build; the cluster statistics use
+    the same tables in between (abi_statistics.inl).  Three builds of different sets with statistics between them: every
+    leaf count equals the oracle's tree."""
+    import badger_amcl_amd as bpf
+    rng = np.random.default_rng(23)
+    n = 40000
+    for k in range(3):
+        s = np.zeros((n, 4))
+        s[:, 0] = rng.uniform(0, 60 + 20 * k, n); s[:, 1] = rng.uniform(0, 80, n); s[:, 2] = rng.uniform(-3.1, 3.1, n)
+        s[:, 3] = 1.0 / n
+        otree = orc.ParticleFilter(100, n, 0.0, 0.0, 85.0, seed=1)
+        otree.set_samples(s)
+        pf = bpf.ParticleFilter(engine, 100, n, 0.0, 0.0, 85.0)
+        pf.initWithSamples(s)
+        st = pf.getState()
+        assert engine.kld_last_form() == 2
+        assert st.leaf_count == otree.leaf_count
+        want = _oracle_stats(orc, s, n)
+        # (runs on the tables the tree has just left cleared; the set spans 80 m: its covariance sums carry x^2 ~ 6e3)
+        _assert_stats_equal(pf, want, exact=False, set_atol=1e-8)
