@@ -610,3 +610,69 @@ def test_one_block_resample_declines_keys_beyond_its_packing(engine, orc):
     assert st.kld_on_device == 0
     assert (st.sample_count, st.leaf_count) == (out.sample_count, out.leaf_count)
     assert np.array_equal(pf.getCurrentSet().samples[:, :3], opf.samples[:out.sample_count, :3])
+
+
+@pytest.mark.parametrize("model", ["lf", "gompertz", "prob", "beam"])
+@pytest.mark.parametrize("kind", ["all_max", "all_nan", "one_valid"])
+def test_degenerate_scans_match_oracle(engine, orc, model, kind):
+    """Scans with nothing (or almost nothing) to score: every range at range_max, every range NaN, a single valid
+    return -- the skip rules of planar_scanner.cpp:265-282 and the models' own treatment of max-range readings."""
+    if model == "beam" and kind != "all_max":
+        pytest.skip("the beam model does not skip NaN ranges (planar_scanner.cpp:168-234): NaN in, NaN out")
+    sc_ = Scenario(orc, size=200, n=129, beams=61, cloud="mixture")
+    r = sc_.ranges
+    keep = float(r[17]) if np.isfinite(r[17]) and r[17] < sc_.range_max else 3.0
+    r[:] = sc_.range_max if kind == "all_max" else np.nan
+    if kind == "one_valid":
+        r[17] = keep
+    max_beams = 61 if model != "beam" else 31
+    m, sc, pf, data = sc_.gpu_objects(engine, max_beams, model)
+    got = sc_.samples.copy()
+    total = sc.applyModelToSampleSet(data, got, 0)
+    want = sc_.samples.copy()
+    want_total = sc_.oracle_apply(sc_.oracle_planar(max_beams, model), want)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert rel_err(got[:, 3], want[:, 3]).max() <= W_TOL
+    assert abs(total - want_total) <= 1e-9 * abs(want_total)
+
+
+@pytest.mark.parametrize("resampler", [0, 1])
+@pytest.mark.parametrize("kind", ["one_heavy", "last_heavy", "two_equal", "tiny_set"])
+def test_resample_of_degenerate_weight_vectors_matches_oracle(engine, orc, resampler, kind):
+    """Weight vectors at the edges of the CDF search (particle_filter.cpp:356-420, :443-503): all the mass on the first
+    or on the last sample (zeros everywhere else), two equal masses at the ends, and a set of three samples."""
+    import badger_amcl_amd as bpf
+    rng = np.random.default_rng(5)
+    n = 3 if kind == "tiny_set" else 2000
+    s = np.zeros((n, 4))
+    s[:, 0] = rng.uniform(10, 12, n); s[:, 1] = rng.uniform(20, 22, n); s[:, 2] = rng.uniform(-0.2, 0.2, n)
+    if kind == "one_heavy":
+        s[0, 3] = 1.0
+    elif kind == "last_heavy":
+        s[-1, 3] = 1.0
+    elif kind == "two_equal":
+        s[0, 3] = s[-1, 3] = 0.5
+    else:
+        s[:, 3] = [0.25, 0.5, 0.25]
+    min_s = 2 if kind == "tiny_set" else 100
+    pf = bpf.ParticleFilter(engine, min_s, n, 0.0, 0.0, 85.0)
+    pf.srand48(11)
+    pf.setResampleModel(resampler)
+    pf.initWithSamples(s)
+    st0 = pf.getState()
+    pf.updateResample()
+    after = pf.getCurrentSet()
+    st1 = pf.getState()
+    # No sensor update has run: w_slow = w_fast = 0 and the reference forms w_diff = 1 - 0 / 0 = NaN
+    # (particle_filter.cpp:436-438).  Its multinomial loop treats that as "no random poses" (every comparison with NaN
+    # is false); its systematic one converts NaN to int (:305, undefined behaviour).  The engine takes NaN as 0 in
+    # both; the oracle is given equal averages, which is the same thing without the undefined step
+    # (SURVEY.md Appendix A, 15: the node itself never resamples before it has scored).
+    assert st0.w_slow == 0.0 and st0.w_fast == 0.0
+    opf, out = _oracle_resample_from(orc, s, 1.0, 1.0, st0.leaf_count, 11, resampler, min_s, n)
+    assert out.status == 0 and st1.last_status == 0
+    M = out.sample_count
+    assert st1.sample_count == M and st1.leaf_count == out.leaf_count and st1.bin_count == out.node_count
+    assert np.array_equal(after.samples[:, :3], opf.samples[:M, :3])
+    assert np.all(after.samples[:, 3] == 1.0 / M)
+    assert pf.getRngState() == opf.pf.rng
