@@ -172,3 +172,33 @@ def test_dense_tiled_lut_equals_the_two_level_layout(engine, orc, pitched):
     want = s.copy()
     orc.cloud_apply(op, lut, want, pts[keep])
     assert (rel_err(got[:, 3], want[:, 3]) > 1e-9).sum() <= 1
+
+
+@pytest.mark.parametrize("pitched", [False, True])
+@pytest.mark.parametrize("kind", ["three_points", "all_off_map", "one_particle"])
+def test_cloud_degenerate_inputs_match_oracle(engine, orc, kind, pitched):
+    """A cloud smaller than a wave, a set that stands entirely outside the map (every point of every particle takes
+    the off-map branch, point_cloud_scanner.cpp:132-229 with octomap.cpp:336-355) and a single particle."""
+    import badger_amcl_amd as bpf
+    n = 1 if kind == "one_particle" else 70
+    lut, pts, s, tf_xyz, tf_quat, max_dist = _setup(orc, n, 8, 128, seed=2, pitched=pitched)
+    if kind == "three_points":
+        pts = np.ascontiguousarray(pts[[5, 200, 700]])
+    elif kind == "all_off_map":
+        s[:, 0] += 500.0
+    om = bpf.OctoMap(engine, 0.05)
+    om.setDistancesLUT(lut.pose_indices, lut.distance_ratios, lut.min_cells, lut.max_cells, max_dist)
+    sc = bpf.PointCloudScanner(engine)
+    sc.init(128, om)
+    sc.setPointCloudModel(0.5, 0.05, 0.1)
+    sc.setMapFactors(0.95, 0.95, 0.3)
+    sc.setPointCloudScannerToFootprintTF(tf_xyz, tf_quat)
+    op = orc.cloud(orc.CLOUD_MODEL, 128, tf_xyz, tf_quat, z_hit=0.5, z_rand=0.05, sigma_hit=0.1)
+    op.off_map_factor = 0.95
+    got = s.copy()
+    total = sc.applyModelToSampleSet(bpf.PointCloudData(pts), got)
+    want = s.copy()
+    want_total = orc.cloud_apply(op, lut, want, pts)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert (rel_err(got[:, 3], want[:, 3]) > 1e-9).sum() <= (0 if kind == "all_off_map" else 1)
+    assert abs(total - want_total) <= 1e-9 * abs(want_total)
