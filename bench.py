@@ -441,7 +441,7 @@ class Ctx:
 
 
 def measure(args, ctx, steps, warmup, prewarm, cpu_budget, all_cores=False, host_path=False, profile_mode=1,
-            exchange=None, compare_exchanges=False, prewarm_s=0.25):
+            exchange=None, compare_exchanges=False, prewarm_s=0.25, repeat=False):
     """One engine, one workload: W warm-up steps, K timed steps between fences, the scoring kernel's HIP events, the
     CPU baseline.  Returns the record (rank 0) or None (other ranks)."""
     torch, dist, world, rank = ctx.torch, ctx.dist, ctx.world, ctx.rank
@@ -545,6 +545,13 @@ def measure(args, ctx, steps, warmup, prewarm, cpu_budget, all_cores=False, host
     with Stage("timed region (%s)" % args.model, 600):
         dt = timed(steps)
     prof = e.profile_get()
+    # sub-records: the same K steps once more (ms_per_step_repeat), so that a one-off stall of the shared host inside a
+    # region of a few milliseconds shows as what it is; the record's figures come from the first region
+    dt_repeat = None
+    if repeat:
+        e.profile_enable(0)
+        with Stage("timed region, repeat (%s)" % args.model, 600):
+            dt_repeat = timed(steps)
     # untimed extra pass with every kernel class bracketed, for the per-kernel breakdown
     e.profile_enable(2)
     e.profile_reset()
@@ -613,6 +620,7 @@ def measure(args, ctx, steps, warmup, prewarm, cpu_budget, all_cores=False, host
         "metric": metric_name(args),
         "value": value, "unit": "particle-beam evals/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "prewarm": max(0, prewarm), "ms_per_step": dt / steps * 1e3,
+        **({} if dt_repeat is None else {"ms_per_step_repeat": dt_repeat / steps * 1e3}),
         "higher_is_better": True,
         "scaling": "strong" if getattr(args, "strong_total", None) else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
@@ -744,7 +752,8 @@ def host_buffer_path(wl, sc, pf, data):
             "end_to_end_cycle_ms_unregistered": c_plain * 1e3}
 
 
-SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "prewarm", "ms_per_step", "scaling", "n_gpus", "config",
+SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "prewarm", "ms_per_step", "ms_per_step_repeat", "scaling",
+            "n_gpus", "config",
             "roofline", "cpu_baseline", "kernel_ms_per_step", "exchange_ms", "mailbox_selftest", "rccl_ranks", "setup_s")
 
 
@@ -884,13 +893,13 @@ def main():
                                         (5, max(5, min(args.steps // 2, 12)), 2, 3, 3),
                                         (1, max(200, args.steps), 20, 100, 1)):
                 others.append(sub_record(measure(sub_args(args, config=cfg), ctx, k, w, pw, sub_budget,
-                                                 profile_mode=mode)))
+                                                 profile_mode=mode, repeat=True)))
             line["other_configs"] = others
         # BASELINE configs[3] as worded: 1 M particles TOTAL, 1 M / N per GPU (the N = 1 run is the curve's anchor)
         sa = sub_args(args, strong_total=STRONG_TOTAL)
         sa.particles = STRONG_TOTAL * (rank + 1) // world - STRONG_TOTAL * rank // world
         strong = measure(sa, ctx, max(20, min(args.steps, 60)), 5, 20, sub_budget,
-                         profile_mode=(3 if world == 1 else 1))
+                         profile_mode=(3 if world == 1 else 1), repeat=True)
         if rank == 0:
             line["strong_scaling"] = sub_record(strong)
     if rank == 0:
