@@ -153,11 +153,12 @@ int bpf_planar_set_scanner_pose(bpf_engine* e, const double pose[3]);
  * (0.0 on failure, like the reference); *status (nullable) receives a BPF_* code.
  * ranges/angles/range_count/range_max are PlanarData (planar_scanner.h:45-54);
  * set_converged is PFSampleSet::converged (only the prob model reads it).
- * Sets of 40 k particles or more under a likelihood-field model go through in chunks (BPF_OPT_SEAM_CHUNKS): chunk k
- * is scored while chunk k + 1 crosses PCIe, the scoring launches store the weights into pinned host memory themselves
- * (no download) and the calling thread writes chunk k's weights into the records while chunk k + 1 is scored.  A
- * registered buffer (bpf_host_buffer_register) is read by the copy engine without a staging copy by the caller.
- * Same weights bit for bit as the one-launch form. */
+ * A registered, 16-byte aligned buffer (bpf_host_buffer_register) of 4 096 records or more under a likelihood-field
+ * model is not copied at all: one scoring launch reads the records over PCIe as its waves reach them and writes them
+ * back whole with the new weight.  Other sets of 40 k particles or more go through in two chunks
+ * (BPF_OPT_SEAM_CHUNKS): chunk k is scored while chunk k + 1 crosses PCIe, the scoring launches store the weights into
+ * pinned host memory themselves (no download) and the calling thread writes chunk k's weights into the records while
+ * chunk k + 1 is scored.  Same weights bit for bit as the plain upload / score / download sequence. */
 double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int sample_count, int set_converged,
                                             const double* ranges, const double* angles, int range_count,
                                             double range_max, int* status);
@@ -248,9 +249,11 @@ enum
                                * (hipHostRegister, ~1 ms once) and keeps the registration, keyed by address range.  A
                                * buffer freed or re-allocated under a kept registration makes the next copy fault --
                                * hence off by default; bpf_host_buffer_register is the per-buffer, owner-controlled form */
-  BPF_OPT_SEAM_CHUNKS = 12,   /* default 0 = by size (20 k particles or more per chunk, at most 4): chunks of the pipelined
+  BPF_OPT_SEAM_CHUNKS = 12,   /* default 0 = by size and buffer: a registered, 16-byte aligned buffer of 4 096 records or
+                               * more is read and written IN PLACE by one scoring launch (no copy); otherwise sets of 40 k
+                               * particles or more go up in two chunks; k > 1 forces k chunks (at most 8) of the pipelined
                                * host-buffer seam (bpf_planar_apply_model_to_sample_set); 1 = the plain upload / score /
-                               * download sequence.  Same weights either way. */
+                               * download sequence.  Same weights either way (bpf_seam_last_plan says which ran). */
   BPF_OPT_KLD_LOCAL = 13,     /* default 1: the device-side histogram tree of a long draw stream is grown in LDS-sized pieces
                                * (one block grows the top from the first 2 048 keys, the later keys are routed through it
                                * and blocks grow the subtrees below its nodes: kernels_kld2.hpp) instead of one launch
