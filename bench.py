@@ -830,6 +830,11 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this process has made no GPU call (torch is not even
         # imported yet); it starts the N ranks as children and relays rank 0's JSON line.
+        if os.environ.get("BPF_BENCH_REHEARSAL") == "1" and args.gpus > 4:
+            # all ranks of a rehearsal share ONE GPU; the GPU boxes allow six processes on a card and the launcher
+            # counts as well (a six-rank rehearsal was killed by the box's process guard)
+            sys.stderr.write("bench.py: a rehearsal (all ranks on one GPU) takes at most 4 ranks\n")
+            raise SystemExit(2)
         raise SystemExit(self_launch(args.gpus))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("BPF_FORCE_SHARDED") != "1":
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, os.environ.get("WORLD_SIZE")))
