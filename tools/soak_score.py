@@ -12,68 +12,78 @@ import badger_amcl_amd as bpf
 from oracle import pyoracle as orc
 from scenario import Scenario, rel_err
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-e = bpf.Engine(0)
-t0 = time.time()
-bad_cases = 0
-worst = 0.0
-flips = 0
-for case in range(cases):
-    size = int(rng.choice([64, 100, 200, 333, 400]))
-    n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 257, 1000, 4095, 4096, 4097, 9000]))
-    near = int(rng.choice([64, 128, 192, 512, 576]))
-    beams = int(max(2, rng.choice([2, 3, 7, 61, near - 1, near, near + 1, int(rng.integers(2, 700))])))
-    model = str(rng.choice(["lf", "gompertz", "prob", "beam"]))
-    cloud = str(rng.choice(["converged", "spread", "mixture"]))
-    if n < 2 and cloud == "mixture":
-        cloud = "spread"
-    max_beams = int(rng.choice([beams, max(2, beams // 2), max(2, beams // 3), 30]))
-    if model == "beam":
-        max_beams = max(2, min(max_beams, 64, beams))  # (range_count < max_beams: the reference's step is 0, refused)
-        beams = max(beams, 2)
-        n = min(n, 1000)
-    range_max = float(rng.choice([5.0, 12.0, 30.0]))
-    max_dist = float(rng.choice([0.5, 2.0, 3.5]))
-    pose = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-3.1, 3.1)))
-    factors = (float(rng.uniform(0.5, 1.0)), float(rng.uniform(0.5, 1.0)), float(rng.uniform(0.0, 0.6)))
-    sc_ = Scenario(orc, size=size, n=n, beams=beams, cloud=cloud, max_dist=max_dist, seed=int(rng.integers(1, 10000)),
-                   frac_max=float(rng.choice([0.0, 0.05, 0.5])), frac_nan=(0.0 if model == "beam" else float(rng.choice([0.0, 0.05]))),
-                   scanner_pose=pose, map_factors=factors, range_max=range_max)
-    kw = {}
-    if model in ("lf", "gompertz", "prob"):
-        kw = dict(z_hit=float(rng.uniform(0.3, 0.95)), z_rand=float(rng.uniform(0.01, 0.5)),
-                  sigma_hit=float(rng.uniform(0.05, 0.5)))
-    if model == "prob" and rng.random() < 0.5:
-        kw.update(do_beamskip=1, beam_skip_distance=float(rng.uniform(0.2, 1.0)),
-                  beam_skip_threshold=float(rng.uniform(0.1, 0.6)), beam_skip_error_threshold=float(rng.uniform(0.5, 0.95)))
-    m, sc, pf, data = sc_.gpu_objects(e, max_beams, model, min_samples=min(100, n), model_kw=kw)
-    want = sc_.samples.copy()
-    conv = int(rng.integers(0, 2)) if model == "prob" else 0
-    want_total = sc_.oracle_apply(sc_.oracle_planar(max_beams, model, kw), want, conv)
-    got = sc_.samples.copy()
-    reg = rng.random() < 0.3  # a registered buffer: the in-place form for sets of 4096 and more
-    if reg:
-        e.registerHostBuffer(got)
-    try:
-        total = sc.applyModelToSampleSet(data, got, conv)
-    finally:
+def run(cases=200, seed=1, e=None, quiet=False):
+    """Returns the number of mismatching cases."""
+    rng = np.random.default_rng(seed)
+    own = e is None
+    if own:
+        e = bpf.Engine(0)
+    t0 = time.time()
+    bad_cases = 0
+    worst = 0.0
+    flips = 0
+    for case in range(cases):
+        size = int(rng.choice([64, 100, 200, 333, 400]))
+        n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 257, 1000, 4095, 4096, 4097, 9000]))
+        near = int(rng.choice([64, 128, 192, 512, 576]))
+        beams = int(max(2, rng.choice([2, 3, 7, 61, near - 1, near, near + 1, int(rng.integers(2, 700))])))
+        model = str(rng.choice(["lf", "gompertz", "prob", "beam"]))
+        cloud = str(rng.choice(["converged", "spread", "mixture"]))
+        if n < 2 and cloud == "mixture":
+            cloud = "spread"
+        max_beams = int(rng.choice([beams, max(2, beams // 2), max(2, beams // 3), 30]))
+        if model == "beam":
+            max_beams = max(2, min(max_beams, 64, beams))  # (range_count < max_beams: the reference's step is 0, refused)
+            beams = max(beams, 2)
+            n = min(n, 1000)
+        range_max = float(rng.choice([5.0, 12.0, 30.0]))
+        max_dist = float(rng.choice([0.5, 2.0, 3.5]))
+        pose = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-3.1, 3.1)))
+        factors = (float(rng.uniform(0.5, 1.0)), float(rng.uniform(0.5, 1.0)), float(rng.uniform(0.0, 0.6)))
+        sc_ = Scenario(orc, size=size, n=n, beams=beams, cloud=cloud, max_dist=max_dist, seed=int(rng.integers(1, 10000)),
+                       frac_max=float(rng.choice([0.0, 0.05, 0.5])), frac_nan=(0.0 if model == "beam" else float(rng.choice([0.0, 0.05]))),
+                       scanner_pose=pose, map_factors=factors, range_max=range_max)
+        kw = {}
+        if model in ("lf", "gompertz", "prob"):
+            kw = dict(z_hit=float(rng.uniform(0.3, 0.95)), z_rand=float(rng.uniform(0.01, 0.5)),
+                      sigma_hit=float(rng.uniform(0.05, 0.5)))
+        if model == "prob" and rng.random() < 0.5:
+            kw.update(do_beamskip=1, beam_skip_distance=float(rng.uniform(0.2, 1.0)),
+                      beam_skip_threshold=float(rng.uniform(0.1, 0.6)), beam_skip_error_threshold=float(rng.uniform(0.5, 0.95)))
+        m, sc, pf, data = sc_.gpu_objects(e, max_beams, model, min_samples=min(100, n), model_kw=kw)
+        want = sc_.samples.copy()
+        conv = int(rng.integers(0, 2)) if model == "prob" else 0
+        want_total = sc_.oracle_apply(sc_.oracle_planar(max_beams, model, kw), want, conv)
+        got = sc_.samples.copy()
+        reg = rng.random() < 0.3  # a registered buffer: the in-place form for sets of 4096 and more
         if reg:
-            e.unregisterHostBuffer(got)
-    err = rel_err(got[:, 3], want[:, 3])
-    nb = int((err > 1e-9).sum())
-    budget = 1 + int(n * max_beams * 2e-12)
-    ok = np.array_equal(got[:, :3], want[:, :3]) and nb <= budget and \
-        (abs(total - want_total) <= 1e-9 * abs(want_total) or nb > 0)
-    flips += nb
-    worst = max(worst, float(err[err <= 1e-9].max()) if (err <= 1e-9).any() else 0.0)
-    if not ok:
-        bad_cases += 1
-        print("MISMATCH case %d: size %d n %d beams %d max_beams %d model %s cloud %s kw %s: %d weights off, total %g vs %g"
-              % (case, size, n, beams, max_beams, model, cloud, kw, nb, total, want_total), flush=True)
-    if case % 20 == 19:
-        print("%d cases, %d mismatching, %d knife-edge weights, worst rel err %.2e, %.0f s" %
-              (case + 1, bad_cases, flips, worst, time.time() - t0), flush=True)
-print("%d cases, %d mismatching, %d knife-edge weights within the budget, worst rel err %.2e, %.0f s" %
-      (cases, bad_cases, flips, worst, time.time() - t0))
-sys.exit(1 if bad_cases else 0)
+            e.registerHostBuffer(got)
+        try:
+            total = sc.applyModelToSampleSet(data, got, conv)
+        finally:
+            if reg:
+                e.unregisterHostBuffer(got)
+        err = rel_err(got[:, 3], want[:, 3])
+        nb = int((err > 1e-9).sum())
+        budget = 1 + int(n * max_beams * 2e-12)
+        ok = np.array_equal(got[:, :3], want[:, :3]) and nb <= budget and \
+            (abs(total - want_total) <= 1e-9 * abs(want_total) or nb > 0)
+        flips += nb
+        worst = max(worst, float(err[err <= 1e-9].max()) if (err <= 1e-9).any() else 0.0)
+        if not ok:
+            bad_cases += 1
+            print("MISMATCH case %d: size %d n %d beams %d max_beams %d model %s cloud %s kw %s: %d weights off, total %g vs %g"
+                  % (case, size, n, beams, max_beams, model, cloud, kw, nb, total, want_total), flush=True)
+        if case % 20 == 19:
+            print("%d cases, %d mismatching, %d knife-edge weights, worst rel err %.2e, %.0f s" %
+                  (case + 1, bad_cases, flips, worst, time.time() - t0), flush=True)
+    print("%d cases, %d mismatching, %d knife-edge weights within the budget, worst rel err %.2e, %.0f s" %
+          (cases, bad_cases, flips, worst, time.time() - t0))
+    if own:
+        e.close()
+    return bad_cases
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 200,
+                      int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
