@@ -25,8 +25,8 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, e->d_pose_indices.reserve(n_pose_indices));
   HIPCHK(e, e->d_ratios.reserve(n_distance_ratios));
-  HIPCHK(e, hipMemcpy(e->d_pose_indices.p, pose_indices, n_pose_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(e->d_ratios.p, distance_ratios, n_distance_ratios, hipMemcpyHostToDevice));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_pose_indices.p, pose_indices, n_pose_indices * sizeof(uint32_t)));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_ratios.p, distance_ratios, n_distance_ratios));
   Map3dDev& M = e->map3;
   M.pose_indices = e->d_pose_indices.p;
   M.distance_ratios = e->d_ratios.p;
@@ -125,7 +125,7 @@ int build_lut3d_device(bpf_engine* e, const int* occupied_ijk, size_t n_occupied
   if (n_occupied)
   {
     HIPCHK(e, occ.reserve(3 * n_occupied));
-    HIPCHK(e, hipMemcpyAsync(occ.p, occupied_ijk, 3 * n_occupied * sizeof(int), hipMemcpyHostToDevice, st));
+    H2D_OR_RETURN(h2d_from_host(e, occ.p, occupied_ijk, 3 * n_occupied * sizeof(int), st));
     HIPCHK(e, keys_a.reserve(n_occupied));
     HIPCHK(e, keys_b.reserve(n_occupied));
     hipLaunchKernelGGL(k_lut3d_seed, dim3((unsigned)((n_occupied + 255) / 256)), dim3(256), 0, st, A, (const int*)occ.p,

@@ -74,6 +74,13 @@ void host_buffers_release(bpf_engine* e)
   if (e->copy_up)
     (void)hipStreamDestroy(e->copy_up);
   e->copy_up = nullptr;
+  for (int h = 0; h < 2; ++h)
+  {
+    if (e->bounce_ev[h])
+      (void)hipEventDestroy(e->bounce_ev[h]);
+    e->bounce_ev[h] = nullptr;
+    e->bounce_busy[h] = false;
+  }
 }
 
 int seam_resources(bpf_engine* e)

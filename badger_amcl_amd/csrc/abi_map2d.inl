@@ -62,9 +62,9 @@ int bpf_map2d_set(bpf_engine* e, const int32_t* cells, const float* dist_lut, in
     }
   }
   HIPCHK(e, e->d_cells8.reserve(ncell));
-  HIPCHK(e, hipMemcpy(e->d_cells8.p, e->h_cells8.data(), ncell, hipMemcpyHostToDevice));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_cells8.p, e->h_cells8.data(), ncell));
   HIPCHK(e, e->d_cheb.reserve(cheb.size()));
-  HIPCHK(e, hipMemcpy(e->d_cheb.p, cheb.data(), cheb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_cheb.p, cheb.data(), cheb.size() * sizeof(uint32_t)));
   M.cells8 = e->d_cells8.p;
   M.cheb = e->d_cheb.p;
   M.lut_tiles = nullptr;
@@ -104,7 +104,7 @@ int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, cons
   HIPCHK(e, out.reserve((size_t)n));
   const double* src[5] = { ox, oy, cos_a, sin_a, max_range };
   for (int k = 0; k < 5; ++k)
-    HIPCHK(e, hipMemcpyAsync(in.p + (size_t)k * n, src[k], (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    H2D_OR_RETURN(h2d_from_host(e, in.p + (size_t)k * n, src[k], (size_t)n * sizeof(double), e->stream));
   hipLaunchKernelGGL(k_calc_range, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->map, in.p, in.p + n,
                      in.p + 2 * (size_t)n, in.p + 3 * (size_t)n, in.p + 4 * (size_t)n, n, out.p);
   HIPCHK(e, hipGetLastError());

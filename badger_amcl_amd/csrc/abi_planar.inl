@@ -230,14 +230,20 @@ int apply_model_pipelined(bpf_engine* e, double* samples, int n, int set_converg
   e->tile_sums_n = e->cdf_ready_n = e->cdf_coarse_n = -1;
   HIPCHK(e, e->d_aos.reserve((size_t)n));
   HIPCHK(e, e->scratch.reserve((size_t)n));
-  HIPCHK(e, e->h_aos.reserve((size_t)n));
+  // the weights come back through a FINE-grained pinned array: the scoring launches' stores are written through, so
+  // they are in host memory when the launch behind them (k_seam_done) publishes the chunk's done word.  In a default
+  // (coarse-grained) allocation they may still sit in some XCD's L2 at that point -- nothing but a system-scope
+  // release or a stream synchronisation flushes them, and a kernel's end is neither when another kernel follows --
+  // and this thread would read the previous call's weights (seen once in ~20 runs of the test suite).
+  e->h_seam_w.coherent = true;
+  HIPCHK(e, e->h_seam_w.reserve((size_t)n));
   ScanSlot* s = nullptr;
   FieldScan fs;
   rcode = stage_field_scan(e, ranges, angles, rc, range_max, &s, &fs);
   if (rcode != BPF_OK)
     return rcode;
   e->evals_last = (long long)n * fs.n_valid;
-  double* hw = reinterpret_cast<double*>(e->h_aos.p);
+  double* hw = e->h_seam_w.p;
   const double4* src = reinterpret_cast<const double4*>(samples);
   const unsigned long long gen = ++e->seam_generation;
   // A pinned buffer's FIRST chunk is not copied at all: its prep launch reads the records from host memory itself
@@ -259,8 +265,7 @@ int apply_model_pipelined(bpf_engine* e, double* samples, int n, int set_converg
   // launches instead (the staging of chunk k + 1 then runs beside the scoring of chunk k)
   auto upload = [&](int c) -> int {
     const int lo = lo_of(c), hi = c + 1 == chunks ? n : lo_of(c + 1);
-    HIPCHK(e, hipMemcpyAsync(e->d_aos.p + lo, src + lo, (size_t)(hi - lo) * sizeof(double4), hipMemcpyHostToDevice,
-                             e->copy_up));
+    H2D_OR_RETURN(h2d_from_host(e, e->d_aos.p + lo, src + lo, (size_t)(hi - lo) * sizeof(double4), e->copy_up));
     HIPCHK(e, hipEventRecord(e->seam_ev[c], e->copy_up));
     return BPF_OK;
   };
@@ -369,8 +374,11 @@ double bpf_planar_apply_model_to_sample_set(bpf_engine* e, double* samples, int 
   // the plain sequence: the records go up as they are (one copy), the scoring path's prep launch unpacks them
   HIPCHK_OR(e, e->d_aos.reserve((size_t)sample_count), bail);
   HIPCHK_OR(e, e->scratch.reserve((size_t)sample_count), bail);
-  HIPCHK_OR(e, hipMemcpyAsync(e->d_aos.p, samples, (size_t)sample_count * sizeof(double4), hipMemcpyHostToDevice,
-                              e->stream), bail);
+  {
+    const int rcu = h2d_from_host(e, e->d_aos.p, samples, (size_t)sample_count * sizeof(double4), e->stream);
+    if (rcu != BPF_OK)
+      return bail(rcu);
+  }
   // from here on the copy engine may still be reading the caller's (registered) buffer: no return before it is done
   auto bail_sync = [&](int code) {
     (void)hipStreamSynchronize(e->stream);

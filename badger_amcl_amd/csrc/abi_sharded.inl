@@ -919,6 +919,8 @@ int bpf_set_option(bpf_engine* e, int option, int value)
     e->kld_local = value != 0;
   else if (option == BPF_OPT_TILE_SORT)
     e->tile_sort = value != 0;
+  else if (option == BPF_OPT_HOST_DIRECT_PAGEABLE)
+    e->host_direct = value != 0;
   else if (option == BPF_OPT_STATS_HOST)
   {
     e->stats_host = value != 0;

@@ -51,6 +51,11 @@ struct PinnedBuf
 {
   T* p = nullptr;
   size_t cap = 0;
+  // fine-grained (hipHostMallocCoherent): a kernel's plain stores are written through to host memory.  The default
+  // allocation is coarse-grained on this platform: plain stores may stay in the GPU's L2s until a system-scope
+  // release -- the END of a kernel is not one when another kernel follows in the queue -- so data that the host reads
+  // behind a flag word (and not behind a stream synchronisation) must not live in a default allocation.
+  bool coherent = false;
   PinnedBuf() = default;
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
@@ -63,7 +68,8 @@ struct PinnedBuf
       (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
-    hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(T), hipHostMallocDefault);
+    hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(T),
+                                 coherent ? hipHostMallocCoherent : hipHostMallocDefault);
     if (r == hipSuccess)
       cap = n;
     return r;
@@ -413,6 +419,7 @@ struct bpf_engine
   PinnedBuf<unsigned long long> h_seam_flags;  // [kSeamMaxChunks]: chunk c scored (the launch's generation)
   PinnedBuf<double> h_seam_totals;  // [kSeamMaxChunks]: weight total of chunk c
   unsigned long long seam_generation = 0;
+  PinnedBuf<double> h_seam_w;       // [n] the chunked form's weights on their way back: FINE-grained (see PinnedBuf)
   int last_seam_chunks = 0;         // chunks the last applyModelToSampleSet used (0: the plain sequence)
   bool last_seam_registered = false;
   bool tree_pending = false;        // the current set's histogram tree (leaf / bin counts) has not been built yet
@@ -421,6 +428,13 @@ struct bpf_engine
 
   // ---- tile-sorted scoring of a spread cloud (kernels_window.hpp, HOST_MODE 3 of k_score_field)
   bool tile_sort = true;            // BPF_OPT_TILE_SORT
+  // Pageable host memory on its way up (h2d_from_host, host_common.inl): two pinned halves that this thread fills
+  // while the copy engine empties the other one
+  PinnedBuf<unsigned char> h_bounce;
+  hipEvent_t bounce_ev[2] = { nullptr, nullptr };
+  bool bounce_busy[2] = { false, false };
+  int bounce_next = 0;
+  bool host_direct = false;         // BPF_OPT_HOST_DIRECT_PAGEABLE
   bool spread_init = false;         // the set was initialised with uniform random poses and not resampled since
   DevBuf<int> d_tile_int;           // hist[2][kTileBins] cursor[kTileBins] tile[n] perm[n]
   int tile_parity = 0;              // which half of hist the last tile-sorted update counted into

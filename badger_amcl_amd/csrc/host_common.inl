@@ -1,4 +1,74 @@
 // Host helpers shared by every part of the engine: profiling scopes, drand48 jump tables, LUT encoding.
+// ------------------------------------------------------------------ pageable host memory, host to device
+// hipMemcpy* from PAGEABLE memory of more than a megabyte pins the range on the fly, and the runtime keeps such pins in
+// a small cache keyed by address and size.  A buffer that has been freed and allocated again at the same address -- what
+// an allocator does all day -- then meets a pin of pages that are gone: the copy reads stale data (seen as a weight
+// vector from the previous call in tests/test_gpu_seam_a.py, once in ~20 runs of the suite) or the GPU faults on the
+// host address ("Memory access fault ... Reason: Unknown" at a heap address in tests/test_gpu_soaks.py, one run in
+// five; none in nine runs with the runtime's pinned transfers switched off).  So pageable memory -- the caller's and the
+// engine's own temporaries -- goes up through the engine's own pinned bounce buffer: this thread copies a piece into
+// one half while the copy engine empties the other.  Registered buffers (bpf_host_buffer_register: the owner's
+// promise that the memory stays) and BPF_OPT_HOST_DIRECT_PAGEABLE = 1 (the same promise for every buffer) go to the
+// runtime as they are.  On return the source has been read completely.
+constexpr size_t kBounceHalf = (size_t)2 << 20;
+#define H2D_OR_RETURN(call)   \
+  do                          \
+  {                           \
+    const int _rc = (call);   \
+    if (_rc != BPF_OK)        \
+      return _rc;             \
+  } while (0)
+
+int h2d_from_host(bpf_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st);
+
+// the same, and the device has it when the call returns (where a plain hipMemcpy stood)
+int h2d_from_host_sync(bpf_engine* e, void* dst, const void* src, size_t bytes)
+{
+  const int rc = h2d_from_host(e, dst, src, bytes, e->stream);
+  if (rc != BPF_OK)
+    return rc;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return BPF_OK;
+}
+
+int h2d_from_host(bpf_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+  if (bytes == 0)
+    return BPF_OK;
+  bool direct = e->host_direct;
+  if (!direct)
+  {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(src);
+    for (const auto& r : e->host_regs)
+      direct = direct || (a >= r.base && a + bytes <= r.base + r.bytes);
+  }
+  if (direct)
+  {
+    HIPCHK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    return BPF_OK;
+  }
+  HIPCHK(e, e->h_bounce.reserve(2 * kBounceHalf));
+  for (int h = 0; h < 2; ++h)
+    if (e->bounce_ev[h] == nullptr)
+      HIPCHK(e, hipEventCreateWithFlags(&e->bounce_ev[h], hipEventDisableTiming));
+  const unsigned char* s = static_cast<const unsigned char*>(src);
+  unsigned char* d = static_cast<unsigned char*>(dst);
+  for (size_t off = 0; off < bytes; off += kBounceHalf)
+  {
+    const size_t piece = std::min(kBounceHalf, bytes - off);
+    const int h = e->bounce_next;
+    e->bounce_next ^= 1;
+    if (e->bounce_busy[h])
+      HIPCHK(e, hipEventSynchronize(e->bounce_ev[h]));  // (the copy that last read this half)
+    unsigned char* half = e->h_bounce.p + (size_t)h * kBounceHalf;
+    std::memcpy(half, s + off, piece);
+    HIPCHK(e, hipMemcpyAsync(d + off, half, piece, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipEventRecord(e->bounce_ev[h], st));
+    e->bounce_busy[h] = true;
+  }
+  return BPF_OK;
+}
+
 // ------------------------------------------------------------------ profiling helpers
 struct ProfScope
 {
@@ -131,11 +201,11 @@ int encode_lut(bpf_engine* e, const float* lut)
     }
   }
   HIPCHK(e, e->d_lut_tiles.reserve(tiles.size()));
-  HIPCHK(e, hipMemcpy(e->d_lut_tiles.p, tiles.data(), tiles.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_lut_tiles.p, tiles.data(), tiles.size() * sizeof(uint16_t)));
   HIPCHK(e, e->d_levels.reserve(levels.size() + 1));
-  HIPCHK(e, hipMemcpy(e->d_levels.p, levels.data(), levels.size() * sizeof(float), hipMemcpyHostToDevice));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_levels.p, levels.data(), levels.size() * sizeof(float)));
   HIPCHK(e, e->d_lut_f32.reserve(ncell));
-  HIPCHK(e, hipMemcpy(e->d_lut_f32.p, lut, ncell * sizeof(float), hipMemcpyHostToDevice));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_lut_f32.p, lut, ncell * sizeof(float)));
   e->h_levels = levels;
   e->h_lut_f32.assign(lut, lut + ncell);
   e->map.lut_tiles = e->d_lut_tiles.p;

@@ -179,7 +179,7 @@ int ensure_free_space(bpf_engine* e, FreeSpaceDev* out)
     e->n_free = (int)ij.size();
     HIPCHK(e, e->d_free_ij.reserve(std::max<size_t>(ij.size(), 1)));
     if (!ij.empty())
-      HIPCHK(e, hipMemcpy(e->d_free_ij.p, ij.data(), ij.size() * sizeof(int2), hipMemcpyHostToDevice));
+      H2D_OR_RETURN(h2d_from_host_sync(e, e->d_free_ij.p, ij.data(), ij.size() * sizeof(int2)));
     e->free_map_version = e->map_version;
     e->free_radius = radius;
   }
@@ -274,7 +274,7 @@ int ensure_fused_jump(bpf_engine* e)
     jt[m].c = c;
   }
   HIPCHK(e, e->d_fused_jump.reserve(kFusedWindow));
-  HIPCHK(e, hipMemcpy(e->d_fused_jump.p, jt.data(), jt.size() * sizeof(FusedJump), hipMemcpyHostToDevice));
+  H2D_OR_RETURN(h2d_from_host_sync(e, e->d_fused_jump.p, jt.data(), jt.size() * sizeof(FusedJump)));
   HIPCHK(e, e->d_fused_keys.reserve(kFusedWindow));
   HIPCHK(e, e->d_fused_counter.reserve(1));
   // on the engine's stream: a plain hipMemset may still be in flight when the first launch counts its blocks
@@ -431,7 +431,7 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
   HIPCHK(e, e->d_kld_counts.reserve((size_t)n));
   HIPCHK(e, e->d_kld_tiles.reserve((size_t)tiles));
   HIPCHK(e, e->d_kld_flags.reserve(4 + kMaxLevels));
-  HIPCHK(e, e->h_kld.reserve(4 + kMaxLevels));
+  HIPCHK(e, e->h_kld.reserve(4 + kMaxLevels + 16));  // (+ the pieces form's eight result words)
   ProfScope ps(e, BPF_K_DRAW);
   KldArgs K{};
   K.keys = e->d_keys.p;
@@ -563,9 +563,11 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
     L.whole_stream = whole_stream ? 1 : 0;
     e->kld_generation = (e->kld_generation % 0x3fffffff) + 1;
     L.generation = e->kld_generation;
-    volatile int* res = e->h_kld.p + 16;
-    res[0] = 0;
-    L.result_host = res;
+    // (eight 64-bit words behind the level loop's flag words in the pinned block)
+    static_assert((4 + kMaxLevels) % 2 == 0, "the result words are 8-byte aligned");
+    volatile unsigned long long* words = reinterpret_cast<volatile unsigned long long*>(e->h_kld.p + 4 + kMaxLevels);
+    L.result_host = e->h_kld.p + 4 + kMaxLevels;
+    int res[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     hipLaunchKernelGGL(k_kld2_init, dim3(n_tiles), dim3(256), 0, e->stream, K, tile_first);
     hipLaunchKernelGGL(k_kld2_compact, dim3(n_tiles), dim3(256), 0, e->stream, L);
     hipLaunchKernelGGL(k_kld2_top, dim3(1), dim3(kKld2Block), kKld2LdsBytes, e->stream, L);
@@ -587,14 +589,24 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
     hipLaunchKernelGGL(k_kld_clear, dim3(std::min(1024, blocks_for((int)table, 256))), block, 0, e->stream, K, table,
                        4 + kMaxLevels, 0);
     HIPCHK(e, hipGetLastError());
-    // the result block in pinned memory, its generation word last: one poll instead of three copies with a
-    // stream synchronisation each
+    // the result block in pinned memory, every word tagged with the generation: one poll instead of three copies
+    // with a stream synchronisation each
     {
+      auto all_there = [&]() {
+        for (int k = 1; k < 8; ++k)
+        {
+          const unsigned long long w = __atomic_load_n(const_cast<unsigned long long*>(words + k), __ATOMIC_ACQUIRE);
+          if ((unsigned)(w >> 32) != (unsigned)L.generation)
+            return false;
+          res[k] = (int)(unsigned)w;
+        }
+        return true;
+      };
       const auto t0 = std::chrono::steady_clock::now();
       bool seen = false;
       for (unsigned spins = 0; !seen; ++spins)
       {
-        seen = __atomic_load_n(e->h_kld.p + 16, __ATOMIC_ACQUIRE) == L.generation;
+        seen = all_there();
         if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100))
           break;
         if (!seen)
@@ -603,7 +615,7 @@ int kld_tree_on_device(bpf_engine* e, int maxs, bool* handled, int* stop_out, in
       if (!seen)
       {
         HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (__atomic_load_n(e->h_kld.p + 16, __ATOMIC_ACQUIRE) != L.generation)
+        if (!all_there())
           return e->fail(BPF_ERR_HIP, "k_kld2_result did not publish its result");
       }
     }
@@ -1002,7 +1014,7 @@ int upload_samples(bpf_engine* e, const double* aos, int n, SampleSet& dst)
   HIPCHK(e, dst.reserve((size_t)n));
   // the caller's (pageable) buffer straight to the runtime, which pipelines its own bounce buffers: a staging memcpy of
   // the whole set on this thread followed by one DMA serialises the two (0.37 against 0.31 ms per update at 100 k)
-  HIPCHK(e, hipMemcpyAsync(e->d_aos.p, aos, (size_t)n * sizeof(double4), hipMemcpyHostToDevice, e->stream));
+  H2D_OR_RETURN(h2d_from_host(e, e->d_aos.p, aos, (size_t)n * sizeof(double4), e->stream));
   hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->d_aos.p, dst.dev(), n);
   HIPCHK(e, hipGetLastError());
   return BPF_OK;

@@ -55,7 +55,7 @@ struct Kld2Args
   int* fill;       // [kKld2Nodes]
   int* bk;         // [n] tkeys positions grouped by bucket
   int* status;     // [0] BPF_KLD2_*, [1] largest bucket
-  // result for the host (k_kld2_result): pinned words, [0] = generation last
+  // result for the host (k_kld2_result): eight 64-bit pinned words, (generation << 32) | value in words 1 .. 7
   volatile int* result_host;
   int generation;
   int whole_stream;
@@ -618,16 +618,18 @@ __global__ void k_kld2_result(const Kld2Args A)
   const int stop = A.whole_stream ? -1 : A.K.flags[2];
   const int M = (stop >= 1 && stop <= n) ? stop : n;
   const int2 c = A.counts[M - 1];
-  volatile int* out = A.result_host;
-  out[1] = A.K.flags[0];
-  out[2] = (stop >= 1 && stop <= n) ? stop : -1;
-  out[3] = c.x;
-  out[4] = c.y;
-  out[5] = A.status[0];
-  out[6] = *A.n_tkeys;
-  out[7] = A.status[1];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __hip_atomic_store(const_cast<int*>(out), A.generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // Seven 64-bit words in pinned memory, each (generation << 32) | value, each a system-scope store of its own -- as
+  // fused_publish does it.  (Plain stores followed by a flag word are NOT enough: they may stay in this XCD's L2 --
+  // the default pinned allocation is coarse-grained -- while the flag, written through, is already in host memory; the
+  // host then reads the PREVIOUS build's stop / leaf count.  A build over 60 000 draws followed by one over 100 showed
+  // it as a sample count beyond the new filter's buffers.)
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(const_cast<int*>(A.result_host));
+  const unsigned long long g = (unsigned long long)(unsigned)A.generation << 32;
+  const int v[8] = { 0, A.K.flags[0], (stop >= 1 && stop <= n) ? stop : -1, c.x, c.y, A.status[0], *A.n_tkeys,
+                     A.status[1] };
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    __hip_atomic_store(&out[k], g | (unsigned long long)(unsigned)v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace bpf

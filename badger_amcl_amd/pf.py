@@ -33,6 +33,7 @@ OPT_HOST_AUTO_REGISTER = 11
 OPT_SEAM_CHUNKS = 12
 OPT_KLD_LOCAL = 13
 OPT_TILE_SORT = 14
+OPT_HOST_DIRECT_PAGEABLE = 15  # pageable buffers straight to the HIP runtime (the caller promises they never move)
 CELL_FREE, CELL_UNKNOWN, CELL_OCCUPIED = -1, 0, 1
 
 

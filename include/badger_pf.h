@@ -262,6 +262,13 @@ enum
                                * uniformly is scored in map-tile order, each XCD taking a contiguous eighth of it, when the
                                * map's LUT does not fit an XCD's L2 (tile-sorted scoring); 0 = index
                                * order always.  Same weights. */
+  BPF_OPT_HOST_DIRECT_PAGEABLE = 15, /* default 0: pageable host memory (unregistered sample buffers, map and cloud arrays)
+                               * goes up through the engine's own pinned bounce buffer, one host copy.  1 = it is handed
+                               * to the HIP runtime as it is (faster by that copy), which pins ranges of more than a
+                               * megabyte on the fly and KEEPS such pins, keyed by address and size: the caller's
+                               * promise that no buffer it passes is ever freed and allocated again at the same address
+                               * while the engine lives (a stale pin reads old pages or faults).  Registered buffers
+                               * (bpf_host_buffer_register) are always direct. */
   BPF_OPT_FUSED_RESAMPLE = 5  /* default 1: normalisation + CDF in one launch, and a resample whose candidate stream
                                * fits 4096 draws as one single-block launch (draws, KLD stop rule, weights,
                                * updateConverged); 0 = the separate launches with the host's ordered replay.

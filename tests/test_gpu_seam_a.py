@@ -71,7 +71,11 @@ def test_pipelined_form_equals_the_plain_sequence_and_the_oracle(engine, big):
                     engine.set_option(bpf.pf.OPT_SEAM_CHUNKS, 0)
                 # same kernels on the same particles: the weights are the same bits; the total is the sum of the
                 # chunks' totals, the plain sequence's one fixed-shape sum
-                assert np.array_equal(buf, plain) and abs(total - t_plain) <= 1e-13 * t_plain
+                diff = np.flatnonzero((buf != plain).any(axis=1))
+                assert diff.size == 0 and abs(total - t_plain) <= 1e-13 * t_plain, (
+                    "chunks %d pinned %s: %d rows differ, first %s last %s; row %s vs %s; total %r vs %r" % (
+                        chunks, pinned, diff.size, diff[:4], diff[-4:], buf[diff[0]] if diff.size else None,
+                        plain[diff[0]] if diff.size else None, total, t_plain))
     finally:
         engine.unregisterHostBuffer(reg)
 
