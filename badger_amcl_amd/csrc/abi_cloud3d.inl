@@ -215,8 +215,8 @@ int build_lut3d_device(bpf_engine* e, const int* occupied_ijk, size_t n_occupied
   HIPCHK(e, hipGetLastError());
   std::vector<uint32_t> pose_indices(n_cols);
   std::vector<uint8_t> ratios(n_ratios);
-  HIPCHK(e, hipMemcpyAsync(pose_indices.data(), d_pose.p, n_cols * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIPCHK(e, hipMemcpyAsync(ratios.data(), d_ratios.p, n_ratios, hipMemcpyDeviceToHost, st));
+  H2D_OR_RETURN(d2h_to_host(e, pose_indices.data(), d_pose.p, n_cols * sizeof(uint32_t), st));
+  H2D_OR_RETURN(d2h_to_host(e, ratios.data(), d_ratios.p, n_ratios, st));
   HIPCHK(e, hipStreamSynchronize(st));
   e->lut3d_generations = (int)generation - 1;
   *handled = true;
@@ -365,13 +365,13 @@ int bpf_map3d_get_distances_lut(bpf_engine* e, uint32_t* pose_indices, size_t po
   {
     if (pose_capacity < e->n_pose_indices)
       return e->fail(BPF_ERR_CAPACITY, "pose_indices output too small");
-    HIPCHK(e, hipMemcpy(pose_indices, e->d_pose_indices.p, e->n_pose_indices * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    H2D_OR_RETURN(d2h_to_host(e, pose_indices, e->d_pose_indices.p, e->n_pose_indices * sizeof(uint32_t), e->stream));
   }
   if (distance_ratios)
   {
     if (ratios_capacity < e->n_ratios)
       return e->fail(BPF_ERR_CAPACITY, "distance_ratios output too small");
-    HIPCHK(e, hipMemcpy(distance_ratios, e->d_ratios.p, e->n_ratios, hipMemcpyDeviceToHost));
+    H2D_OR_RETURN(d2h_to_host(e, distance_ratios, e->d_ratios.p, e->n_ratios, e->stream));
   }
   return BPF_OK;
 }

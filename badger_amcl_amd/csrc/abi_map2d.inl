@@ -108,8 +108,7 @@ int bpf_map2d_calc_range(bpf_engine* e, const double* ox, const double* oy, cons
   hipLaunchKernelGGL(k_calc_range, dim3(blocks_for(n, 256)), dim3(256), 0, e->stream, e->map, in.p, in.p + n,
                      in.p + 2 * (size_t)n, in.p + 3 * (size_t)n, in.p + 4 * (size_t)n, n, out.p);
   HIPCHK(e, hipGetLastError());
-  HIPCHK(e, hipMemcpyAsync(range_out, out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  H2D_OR_RETURN(d2h_to_host(e, range_out, out.p, (size_t)n * sizeof(double), e->stream));
   return BPF_OK;
 }
 
@@ -123,7 +122,6 @@ int bpf_map2d_get_distances_lut(bpf_engine* e, float* out, size_t capacity)
   if (capacity < ncell)
     return e->fail(BPF_ERR_CAPACITY, "output too small");
   HIPCHK(e, hipSetDevice(e->device));
-  HIPCHK(e, hipMemcpyAsync(out, e->d_lut_f32.p, ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  H2D_OR_RETURN(d2h_to_host(e, out, e->d_lut_f32.p, ncell * sizeof(float), e->stream));
   return BPF_OK;
 }

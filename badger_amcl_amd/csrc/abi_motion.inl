@@ -205,8 +205,7 @@ int build_set_tree(bpf_engine* e, int n)
   if (!handled)
   {
     std::vector<int> keys((size_t)n * 3);
-    HIPCHK(e, hipMemcpyAsync(keys.data(), e->d_keys.p, keys.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    H2D_OR_RETURN(d2h_to_host(e, keys.data(), e->d_keys.p, keys.size() * sizeof(int), e->stream));
     e->hist.clear();
     for (int i = 0; i < n; ++i)
       e->hist.insert(keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2]);

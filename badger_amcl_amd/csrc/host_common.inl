@@ -21,6 +21,59 @@ constexpr size_t kBounceHalf = (size_t)2 << 20;
 
 int h2d_from_host(bpf_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st);
 
+// The way down into PAGEABLE memory (a destination of more than a megabyte is pinned and cached by the runtime just
+// the same): piece by piece into the bounce buffer and from there by this thread.  Everything queued on `st` before
+// the call is done when it returns, and so is the copy.
+int d2h_to_host(bpf_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+  if (bytes == 0)
+    return BPF_OK;
+  bool direct = e->host_direct;
+  if (!direct)
+  {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(dst);
+    for (const auto& r : e->host_regs)
+      direct = direct || (a >= r.base && a + bytes <= r.base + r.bytes);
+  }
+  if (direct)
+  {
+    HIPCHK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    return BPF_OK;
+  }
+  HIPCHK(e, e->h_bounce.reserve(2 * kBounceHalf));
+  for (int h = 0; h < 2; ++h)
+  {
+    if (e->bounce_ev[h] == nullptr)
+      HIPCHK(e, hipEventCreateWithFlags(&e->bounce_ev[h], hipEventDisableTiming));
+    if (e->bounce_busy[h])
+      HIPCHK(e, hipEventSynchronize(e->bounce_ev[h]));  // (an upload that may still be reading this half)
+    e->bounce_busy[h] = false;
+  }
+  unsigned char* d = static_cast<unsigned char*>(dst);
+  const unsigned char* s = static_cast<const unsigned char*>(src);
+  // two pieces in flight: the copy engine fills one half while this thread empties the other
+  size_t issued = 0, taken = 0;
+  int h_issue = 0, h_take = 0;
+  while (taken < bytes)
+  {
+    while (issued < bytes && issued - taken < 2 * kBounceHalf)
+    {
+      const size_t piece = std::min(kBounceHalf, bytes - issued);
+      HIPCHK(e, hipMemcpyAsync(e->h_bounce.p + (size_t)h_issue * kBounceHalf, s + issued, piece, hipMemcpyDeviceToHost, st));
+      HIPCHK(e, hipEventRecord(e->bounce_ev[h_issue], st));
+      issued += piece;
+      h_issue ^= 1;
+    }
+    const size_t piece = std::min(kBounceHalf, bytes - taken);
+    HIPCHK(e, hipEventSynchronize(e->bounce_ev[h_take]));
+    std::memcpy(d + taken, e->h_bounce.p + (size_t)h_take * kBounceHalf, piece);
+    taken += piece;
+    h_take ^= 1;
+  }
+  return BPF_OK;
+}
+
 // the same, and the device has it when the call returns (where a plain hipMemcpy stood)
 int h2d_from_host_sync(bpf_engine* e, void* dst, const void* src, size_t bytes)
 {
@@ -233,8 +286,7 @@ int build_lut_device(bpf_engine* e, double max_dist)
                      max_dist, e->d_lut_f32.p);
   HIPCHK(e, hipGetLastError());
   std::vector<float> lut(ncell);
-  HIPCHK(e, hipMemcpyAsync(lut.data(), e->d_lut_f32.p, ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  H2D_OR_RETURN(d2h_to_host(e, lut.data(), e->d_lut_f32.p, ncell * sizeof(float), e->stream));
   e->map.max_dist = max_dist;
   return encode_lut(e, lut.data());
 }
