@@ -1,7 +1,9 @@
 // C-ABI: caller-owned host buffers (the reference keeps its particles in a host std::vector<PFSample> that is
 // allocated once, particle_filter.cpp:62-89, and hands it to the sensor model every cycle).
 // ---------------------------------------------------------------------- host buffers
-// A pageable buffer crosses PCIe through the runtime's pinning / bounce path: 3.2 MB go up at the link's rate too
+// A pageable buffer crosses PCIe through the ENGINE's bounce buffer (h2d_from_host, host_common.inl: the runtime's own
+// on-the-fly pinning keeps stale pins of buffers that were freed and allocated again); handed to the runtime directly
+// (BPF_OPT_HOST_DIRECT_PAGEABLE) 3.2 MB go up at the link's rate too
 // (64 us, tools/ubench/pcie_probe.hip), but the calling thread is busy inside the call for that long and a download
 // into it takes 44 us per 0.8 MB instead of 22; a buffer pinned with hipHostRegister is read and written by the copy
 // engine -- or by a kernel -- directly, with the calling thread free.  Registration costs 60 us to a millisecond, so
