@@ -152,7 +152,7 @@ def test_a_buffer_that_moves_between_calls(engine, big):
     engine.unregisterHostBuffer(a)
     del a
     gc.collect()
-    for k in range(3):
+    for k in range(12):
         c = sc_.samples.copy()   # the allocator may hand A's pages out again
         c[:, 3] *= (k + 2.0)     # different contents each time: a stale mapping would show
         total = sc.applyModelToSampleSet(data, c, 0)
@@ -249,3 +249,24 @@ def test_the_tree_of_an_adopted_set_is_built_when_it_is_first_needed(engine, orc
         out = opf.update_resample()
         assert (st.sample_count, st.leaf_count) == (out.sample_count, out.leaf_count)
     pf.setResampleModel(0)
+
+
+def test_pageable_buffers_that_come_and_go(engine):
+    """Sets of more than a megabyte in pageable memory that is freed and allocated again between the calls -- the
+    allocator hands the same addresses out again, and a cache of on-the-fly pins keyed by address (the HIP runtime
+    keeps one for pageable copies) would read the pages of a buffer that is gone: every set that goes in comes back
+    out, bit for bit (pageable memory goes through the engine's own bounce buffer, host_common.inl)."""
+    import badger_amcl_amd as bpf
+    rng = np.random.default_rng(3)
+    n = 60000
+    pf = bpf.ParticleFilter(engine, 100, n, 0.0, 0.0, 85.0)
+    for k in range(25):
+        s = rng.uniform(-50.0, 50.0, (n, 4))
+        s[:, 3] = rng.uniform(0.1, 1.0, n)
+        pf.initWithSamples(s, leaf_count=1)
+        want = s.copy()
+        del s
+        junk = np.full((n, 4), float(k))  # quite possibly where s was
+        got = pf.getCurrentSet().samples
+        assert np.array_equal(got, want), k
+        del junk, got
