@@ -746,6 +746,8 @@ def host_buffer_path(wl, sc, pf, data):
                      "scoring launches and written into the records chunk by chunk" % (wl["n"] * 32 / 1e6, chunks)),
             "pinned": bool(pinned), "chunks": chunks,
             "ms_per_update_unregistered": d_plain * 1e3,
+            "unregistered_is": ("the same buffer as plain pageable memory: it goes up through the engine's own pinned bounce "
+                                "buffer (BPF_OPT_HOST_DIRECT_PAGEABLE = 0), in two chunks for a set of this size"),
             # the whole cycle with the set crossing PCIe both ways (SURVEY 8(d)'s end-to-end figure): H2D of the set
             # (32 B/particle), sensor update, resample, D2H of the resampled set -- never `value` either
             "end_to_end_cycle_ms": dte * 1e3, "end_to_end_evals_per_s": evals / dte,
