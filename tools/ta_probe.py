@@ -6,15 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench
 import badger_amcl_amd as bpf
 class A: pass
-args = A(); args.map_size=2000; args.beams=1081; args.particles=100000; args.cloud="converged"; args.model="lf"; args.resampler="multinomial"
+args = A(); args.map_size=2000; args.beams=1081; args.particles=100000; args.cloud="converged"; args.model="lf"; args.resampler="multinomial"; args.lut="reference"; args.motion="none"; args.config=None; args.strong_total=None
 wl = bench.build_workload(args, 0); wl["world"]=1
 e, m, sc, pf, data, lut = bench.setup_engine(args, wl, 0)
 e.set_option(2, 0)
 def run(d, label):
-    for _ in range(3):
+    for _ in range(300):
         pf.restore(); sc.updateSensor(pf, d)
-    e.synchronize(); e.profile_enable(1); e.profile_reset()
-    for _ in range(20):
+    e.synchronize(); e.profile_enable(3); e.profile_reset()
+    for _ in range(100):
         pf.restore(); sc.updateSensor(pf, d)
     e.synchronize(); p = e.profile_get(); e.profile_enable(0)
     print(label, "score kernel us:", round(p["score"]["ms"]/p["score"]["launches"]*1e3,1))
