@@ -10,7 +10,14 @@ args = A(); args.map_size=2000; args.beams=1081; args.particles=100000; args.clo
 wl = bench.build_workload(args, 0); wl["world"]=1
 e, m, sc, pf, data, lut = bench.setup_engine(args, wl, 0)
 e.set_option(2, 0)
-def run(d, label):
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None   # one scan only, few launches: for a rocprofv3 --pmc pass (tools/exp/ta_pmc.sh)
+def run(d, label, key):
+    if ONLY is not None:
+        if ONLY == key:
+            for _ in range(6):
+                pf.restore(); sc.updateSensor(pf, d)
+            e.synchronize()
+        return
     for _ in range(300):
         pf.restore(); sc.updateSensor(pf, d)
     e.synchronize(); e.profile_enable(3); e.profile_reset()
@@ -18,10 +25,10 @@ def run(d, label):
         pf.restore(); sc.updateSensor(pf, d)
     e.synchronize(); p = e.profile_get(); e.profile_enable(0)
     print(label, "score kernel us:", round(p["score"]["ms"]/p["score"]["launches"]*1e3,1))
-run(data, "real scan")
+run(data, "real scan", "real")
 same = bpf.PlanarData(np.full(1081, 4.0), np.full(1081, 0.3), 30.0)
-run(same, "all beams identical")
+run(same, "all beams identical", "same")
 arc = bpf.PlanarData(np.full(1081, 4.0), wl["angles"], 30.0)
-run(arc, "constant range arc")
+run(arc, "constant range arc", "arc")
 short = bpf.PlanarData(np.full(1081, 0.5), wl["angles"], 30.0)
-run(short, "0.5 m arc")
+run(short, "0.5 m arc", "short")
