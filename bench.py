@@ -406,6 +406,8 @@ def pmc_evidence(model, cloud, k_ms, n, beams):
     if rec.get("issue_frac") is not None:
         out["issue_frac"] = rec["issue_frac"]  # SQ_ACTIVE_INST_VALU x 4 cycles / SIMDs / kernel cycles, that run
         out["bound"] = rec.get("bound", "valu_issue")
+        if rec.get("bound_note"):
+            out["bound_is"] = rec["bound_note"]
     if out.get("hbm_measured_gbs", 0.0) >= 0.5 * HBM_PEAK_GBS:
         # the L2s fetch at more than half the HBM peak (FETCH_SIZE counts every L2 fill, Infinity-Cache hits included):
         # the spread cloud, whose particles put the whole LUT through every XCD's 4 MB L2
