@@ -638,7 +638,7 @@ def measure(args, ctx, steps, warmup, prewarm, cpu_budget, all_cores=False, host
                        else "collective (%s)" % collective_is))},
         # `achieved` is ALGORITHMIC GB/s (bytes the reference's formulation moves per launch / the
         # kernel's duration), `frac` its fraction of the HBM peak; `bound` is what the PMC passes show limits the
-        # kernel (valu_issue: the LUT working set is L2-resident, see issue_frac / hbm_measured_gbs); None = no PMC
+        # kernel (valu_issue / l1_access_rate: the LUT working set is L2-resident, see issue_frac / hbm_measured_gbs / bound_is); None = no PMC
         # pass of this workload is committed, so nothing is claimed
         "roofline": {"bound": ev["bound"], "kernel": e.score_kernel_name(), "achieved": achieved,
                      "achieved_is": "algorithmic GB/s", "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -42,6 +42,8 @@ def main():
         rec["bound"] = "valu_issue" if rec["issue_frac"] >= 0.5 else "latency"
     if d.get("TCP_TOTAL_CACHE_ACCESSES_sum") and d.get("SQ_INSTS_VMEM_RD"):
         rec["l1_accesses_per_gather"] = d["TCP_TOTAL_CACHE_ACCESSES_sum"] / d["SQ_INSTS_VMEM_RD"]
+    # (the headline record's `bound` / `bound_note` were set by hand from the measurements in
+    # profiles/r03_score_field_variants.md: counters of one workload alone do not tell the L1's access rate from issue)
     if d.get("SQ_INSTS_VALU"):
         rec["valu_wave_instructions_per_launch"] = d["SQ_INSTS_VALU"]
     text = json.dumps({key: rec}, indent=1)
