@@ -1,4 +1,7 @@
 // C-ABI: 3-D map + point cloud.
+#ifndef BPF_CLOUD_BORDER
+#define BPF_CLOUD_BORDER 1  // 0 (experiment builds): the planar dense kernel always in its plain form
+#endif
 // ---------------------------------------------------------------------- 3-D map + point cloud
 int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_indices, const uint8_t* distance_ratios,
                   size_t n_distance_ratios, const int min_cells[3], const int max_cells[3], double resolution,
@@ -46,13 +49,27 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
   M.dense = nullptr;
   M.dense_k = 0;
   M.dense_plane = 0;
+  M.border_code = -1;
   {
-    const long long ntx = (w + 1 + 7) / 8, nty = (h + 1 + 7) / 8;
+    // grid positions 0 .. w + 1 and 0 .. h + 1: the map's cells at (i + 1, j + 1) with a border cell all round
+    const long long ntx = (w + 2 + 7) / 8, nty = (h + 2 + 7) / 8;
     const long long plane = ntx * nty * 64;
     if (plane < (1 << 24) && 8 * ntx - 1 < (1 << 24) && plane * nz <= (1ll << 30))
     {
+      // a distance ratio that no entry of the LUT holds (the highest such) fills the border and the padding: the
+      // scoring kernel's BORDER form reads the off-map term under it.  With max_dist / resolution = 6 a LUT holds
+      // some 30 distinct ratios; one that holds all 256 keeps the plain form.
+      {
+        bool used[256] = {};
+        for (size_t i = 0; i < n_distance_ratios; ++i)
+          used[distance_ratios[i]] = true;
+        for (int c = 255; c >= 0 && M.border_code < 0; --c)
+          if (!used[c])
+            M.border_code = c;
+      }
       HIPCHK(e, e->d_dense3d.reserve((size_t)(plane * nz)));
-      HIPCHK(e, hipMemsetAsync(e->d_dense3d.p, 0xFF, (size_t)(plane * nz), e->stream));
+      HIPCHK(e, hipMemsetAsync(e->d_dense3d.p, M.border_code >= 0 ? M.border_code : 0xFF, (size_t)(plane * nz),
+                               e->stream));
       const size_t total = (size_t)(w * h * nz);
       hipLaunchKernelGGL(k_dense3d_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
                          e->d_pose_indices.p, e->d_ratios.p, (int)w, (int)h, (int)nz, (unsigned)(8 * ntx - 1),
@@ -526,7 +543,12 @@ int score_cloud(bpf_engine* e, ParticlesDev p, int n, const float* points_xyz, i
     const bool dense = e->map3.dense != nullptr && e->cloud_dense;
 #define BPF_CLOUD_LAUNCH(X, P, D) \
   LAUNCH_TIMED(e, BPF_K_SCORE, (k_cloud_score<X, P, D>), dim3(n_chunks, A.slabs), dim3(256), 0, A)
-    if (exact_rinv && planar && dense)
+    const bool border = BPF_CLOUD_BORDER != 0 && planar && dense && e->map3.border_code >= 0;
+    if (exact_rinv && border)
+      LAUNCH_TIMED(e, BPF_K_SCORE, (k_cloud_score<true, true, true, true>), dim3(n_chunks, A.slabs), dim3(256), 0, A);
+    else if (border)
+      LAUNCH_TIMED(e, BPF_K_SCORE, (k_cloud_score<false, true, true, true>), dim3(n_chunks, A.slabs), dim3(256), 0, A);
+    else if (exact_rinv && planar && dense)
       BPF_CLOUD_LAUNCH(true, true, true);
     else if (exact_rinv && planar)
       BPF_CLOUD_LAUNCH(true, true, false);

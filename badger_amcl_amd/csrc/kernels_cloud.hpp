@@ -33,6 +33,9 @@ struct Map3dDev
   const uint8_t* dense;        // nullptr: two-level only
   unsigned dense_k;            // 8 ntx - 1
   unsigned dense_plane;        // bytes per z plane (< 2^24)
+  int border_code;             // >= 0: a distance ratio no cell of the LUT holds; the dense volume's border cells (grid
+                               // positions 0 and size + 1 in x and y) and its padding hold it, and the scoring kernel
+                               // reads the off-map term under it (k_cloud_score, BORDER); -1: every ratio is in use
   int min_c[3], max_c[3];
   int width;
   double resolution;
@@ -194,10 +197,15 @@ __device__ __forceinline__ unsigned clamp_1_to(unsigned c, unsigned hi)
   return r;
 }
 
-template <bool EXACT_RINV, bool PLANAR, bool DENSE>
+// BORDER (with PLANAR and DENSE): an x or y cell off the map is clamped onto the volume's border (grid position 0 or
+// size + 1), whose cells hold Map3dDev::border_code, and the table's entry under that code is the off-map term for the
+// launch -- so the evaluation needs neither the two comparisons against the clamped cells nor the select of `bad`
+// (3 of its ~24 vector instructions, in a kernel whose duration is its instruction count).  Same terms, same order.
+template <bool EXACT_RINV, bool PLANAR, bool DENSE, bool BORDER = false>
 __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
 {
 #pragma clang fp contract(off)
+  static_assert(!BORDER || (PLANAR && DENSE), "BORDER is a form of the planar dense kernel");
 #ifdef BPF_PHASE_TIMING
   const long long _w0 = wall_clock64();
 #endif
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
     }
   }
   for (int i = threadIdx.x; i < 258; i += 256)
-    s_table[i] = (i < 257) ? A.table[i] : 0.0;
+    s_table[i] = (BORDER && i == A.map.border_code) ? A.table[256] : ((i < 257) ? A.table[i] : 0.0);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -316,6 +324,14 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
                                      : voxel1(wx, M.resolution, M.inv_resolution, M.min_c[0]);
       const unsigned cj = EXACT_RINV ? voxel1_exact(wy, M.inv_resolution, hm1)
                                      : voxel1(wy, M.resolution, M.inv_resolution, M.min_c[1]);
+      if (BORDER)
+      {
+        // everything below the map is 0 or "negative" (a huge unsigned), everything above is > span + 1: one unsigned
+        // minimum per axis lands all of it on a border cell
+        const unsigned bi = min(ci, span_x + 2u), bj = min(cj, span_y + 2u);
+        col = (bi << 3) + (__umul24(bj & ~7u, M.dense_k) + bj);
+        return 0u;
+      }
       const unsigned xi = clamp_1_to(ci, span_x + 1u), xj = clamp_1_to(cj, span_y + 1u);
       const bool ok = xi == ci && xj == cj;
       if (DENSE)

@@ -202,3 +202,53 @@ def test_cloud_degenerate_inputs_match_oracle(engine, orc, kind, pitched):
     assert np.array_equal(got[:, :3], want[:, :3])
     assert (rel_err(got[:, 3], want[:, 3]) > 1e-9).sum() <= (0 if kind == "all_off_map" else 1)
     assert abs(total - want_total) <= 1e-9 * abs(want_total)
+
+
+def test_cloud_border_form_equals_plain_form_and_oracle(engine, orc):
+    """The planar dense kernel's BORDER form (off-map x / y cells land on border cells of the dense volume that hold a
+    distance ratio no cell of the LUT uses; the off-map term sits under that ratio in the launch's table) against the
+    plain form (comparisons + select), which a LUT takes when it uses all 256 ratios -- here the same LUT with 256
+    unreferenced bytes 0..255 appended -- and against the oracle.  Particles stand all over and beyond the room, so
+    points leave the map on all four sides; some points are not numbers."""
+    import badger_amcl_amd as bpf
+    lut, pts, s, tf_xyz, tf_quat, max_dist = _setup(orc, 400, 16, 300, seed=9)
+    rng = np.random.default_rng(3)
+    # the room's walls stand at x = +-2 m, y = +-1.5 m (box_room_voxels: +-40 x +-30 cells of 0.05 m) and the map ends
+    # three cells behind them; the cloud reaches 3 m: particles within a metre of a wall (either side of it) see points
+    # on the map, in the border and beyond it, on every side
+    n = s.shape[0]
+    side = rng.integers(0, 4, n)
+    d = rng.uniform(-0.3, 1.0, n)                       # distance inside the wall (negative: outside the room)
+    along = rng.uniform(-1.0, 1.0, n)
+    s[:, 0] = np.where(side == 0, 2.0 - d, np.where(side == 1, -2.0 + d, along * 1.9))
+    s[:, 1] = np.where(side == 2, 1.5 - d, np.where(side == 3, -1.5 + d, along * 1.4))
+    s[:, 2] = rng.uniform(-np.pi, np.pi, n)
+    s[: n // 8, 0] = rng.uniform(-5.0, 5.0, n // 8)     # and some anywhere, far outside included
+    s[: n // 8, 1] = rng.uniform(-4.0, 4.0, n // 8)
+    pts = pts.copy()
+    pts[5, 0] = np.nan
+    pts[77, 2] = np.inf
+    pts[300, 1] = -np.inf
+    assert len(np.unique(lut.distance_ratios)) < 256          # the LUT as built leaves ratios free: BORDER form
+    full = np.concatenate([lut.distance_ratios, np.arange(256, dtype=np.uint8)])
+    out = []
+    for ratios in (lut.distance_ratios, full):
+        om = bpf.OctoMap(engine, 0.05)
+        om.setDistancesLUT(lut.pose_indices, ratios, lut.min_cells, lut.max_cells, max_dist)
+        sc = bpf.PointCloudScanner(engine)
+        sc.init(128, om)
+        sc.setPointCloudModel(0.5, 0.05, 0.1)
+        sc.setMapFactors(0.95, 0.95, 0.3)
+        sc.setPointCloudScannerToFootprintTF(tf_xyz, tf_quat)
+        got = s.copy()
+        total = sc.applyModelToSampleSet(bpf.PointCloudData(pts), got)
+        out.append((got, total))
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0])
+    op = orc.cloud(orc.CLOUD_MODEL, 128, tf_xyz, tf_quat, z_hit=0.5, z_rand=0.05, sigma_hit=0.1)
+    op.off_map_factor = 0.95
+    want = s.copy()
+    want_total = orc.cloud_apply(op, lut, want, pts)
+    bad = rel_err(out[0][0][:, 3], want[:, 3]) > 1e-9
+    assert bad.sum() <= 1, np.flatnonzero(bad)
+    assert abs(out[0][1] - want_total) <= 1e-9 * want_total
+    assert len(np.unique(np.round(want[:, 3] / s[:, 3], 9))) > 30   # the scores differ: walls, free space, off the map
