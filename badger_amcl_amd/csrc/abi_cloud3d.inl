@@ -50,26 +50,37 @@ int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_ind
   M.dense_k = 0;
   M.dense_plane = 0;
   M.border_code = -1;
+  M.zero_code = -1;
   {
     // grid positions 0 .. w + 1 and 0 .. h + 1: the map's cells at (i + 1, j + 1) with a border cell all round
     const long long ntx = (w + 2 + 7) / 8, nty = (h + 2 + 7) / 8;
     const long long plane = ntx * nty * 64;
-    if (plane < (1 << 24) && 8 * ntx - 1 < (1 << 24) && plane * nz <= (1ll << 30))
+    if (plane < (1 << 24) && 8 * ntx - 1 < (1 << 24) && plane * (nz + 1) <= (1ll << 30))
     {
-      // a distance ratio that no entry of the LUT holds (the highest such) fills the border and the padding: the
-      // scoring kernel's BORDER form reads the off-map term under it.  With max_dist / resolution = 6 a LUT holds
-      // some 30 distinct ratios; one that holds all 256 keeps the plain form.
+      // two distance ratios that no entry of the LUT holds (the two highest such): one fills the border and the
+      // padding -- the scoring kernel's BORDER form reads the off-map term under it --, the other one more plane behind
+      // the last, under which the kernel reads 0.0 (the padding lanes of a chunk's last group of points).  With
+      // max_dist / resolution = 6 a LUT holds some 30 distinct ratios; one that leaves fewer than two free keeps the
+      // plain form.
       {
         bool used[256] = {};
         for (size_t i = 0; i < n_distance_ratios; ++i)
           used[distance_ratios[i]] = true;
-        for (int c = 255; c >= 0 && M.border_code < 0; --c)
+        int free2[2] = { -1, -1 }, nf = 0;
+        for (int c = 255; c >= 0 && nf < 2; --c)
           if (!used[c])
-            M.border_code = c;
+            free2[nf++] = c;
+        if (nf == 2)
+        {
+          M.border_code = free2[0];
+          M.zero_code = free2[1];
+        }
       }
-      HIPCHK(e, e->d_dense3d.reserve((size_t)(plane * nz)));
+      HIPCHK(e, e->d_dense3d.reserve((size_t)(plane * (nz + 1))));
       HIPCHK(e, hipMemsetAsync(e->d_dense3d.p, M.border_code >= 0 ? M.border_code : 0xFF, (size_t)(plane * nz),
                                e->stream));
+      HIPCHK(e, hipMemsetAsync(e->d_dense3d.p + (size_t)(plane * nz), M.zero_code >= 0 ? M.zero_code : 0xFF,
+                               (size_t)plane, e->stream));
       const size_t total = (size_t)(w * h * nz);
       hipLaunchKernelGGL(k_dense3d_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
                          e->d_pose_indices.p, e->d_ratios.p, (int)w, (int)h, (int)nz, (unsigned)(8 * ntx - 1),

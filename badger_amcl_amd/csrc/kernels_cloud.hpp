@@ -35,7 +35,10 @@ struct Map3dDev
   unsigned dense_plane;        // bytes per z plane (< 2^24)
   int border_code;             // >= 0: a distance ratio no cell of the LUT holds; the dense volume's border cells (grid
                                // positions 0 and size + 1 in x and y) and its padding hold it, and the scoring kernel
-                               // reads the off-map term under it (k_cloud_score, BORDER); -1: every ratio is in use
+                               // reads the off-map term under it (k_cloud_score, BORDER); -1: fewer than two free ratios
+  int zero_code;               // with border_code: a second free ratio; one more plane behind the volume's last (plane
+                               // index nz + 1) holds it everywhere, the kernel reads 0.0 under it: where the padding
+                               // lanes of a chunk's last group of points gather from
   int min_c[3], max_c[3];
   int width;
   double resolution;
@@ -200,7 +203,9 @@ __device__ __forceinline__ unsigned clamp_1_to(unsigned c, unsigned hi)
 // BORDER (with PLANAR and DENSE): an x or y cell off the map is clamped onto the volume's border (grid position 0 or
 // size + 1), whose cells hold Map3dDev::border_code, and the table's entry under that code is the off-map term for the
 // launch -- so the evaluation needs neither the two comparisons against the clamped cells nor the select of `bad`
-// (3 of its ~24 vector instructions, in a kernel whose duration is its instruction count).  Same terms, same order.
+// (3 of its ~24 vector instructions, in a kernel whose duration is its instruction count).  And the padding lanes behind
+// a chunk's last point gather from one more plane that holds Map3dDev::zero_code, under which the table has 0.0: no
+// `bad` offset is left at all, and the maximum in front of the table read goes too.  Same terms, same order.
 template <bool EXACT_RINV, bool PLANAR, bool DENSE, bool BORDER = false>
 __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
 {
@@ -241,7 +246,8 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
         {
           // the z plane's byte offset; a point whose z is off the map is off the map for every particle: its x is
           // replaced by a coordinate that fails the x test, so the loop needs no flag for it
-          s_pts[2][i] = __uint_as_float(cc * M.dense_plane);
+          // (BORDER: the padding behind the chunk's last point gathers from the plane of zero_code and adds 0.0)
+          s_pts[2][i] = __uint_as_float((BORDER && i >= np) ? (span_z + 2u) * M.dense_plane : cc * M.dense_plane);
           if (cc != c1)
             s_pts[0][i] = 1.0e30f;
         }
@@ -253,7 +259,8 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
     }
   }
   for (int i = threadIdx.x; i < 258; i += 256)
-    s_table[i] = (BORDER && i == A.map.border_code) ? A.table[256] : ((i < 257) ? A.table[i] : 0.0);
+    s_table[i] = (BORDER && i == A.map.border_code) ? A.table[256]
+                 : ((BORDER && i == A.map.zero_code) ? 0.0 : ((i < 257) ? A.table[i] : 0.0));
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -313,7 +320,12 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
       ck = clamp_1_to(cz, span_z + 1u);
       const bool ok = xi == ci && xj == cj && ck == cz;
       if (DENSE)
-        col = __umul24(ck, M.dense_plane) + ((xi << 3) + (__umul24(xj & ~7u, M.dense_k) + xj));
+      {
+        unsigned c2;  // (the multiply-add stated: see cell_xy)
+        const unsigned t = (xi << 3) + xj, xh = xj & ~7u;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(c2) : "v"(xh), "s"(M.dense_k), "v"(t));
+        col = __umul24(ck, M.dense_plane) + c2;
+      }
       else
         col = __umul24(xj, width4) + (xi << 2);
       return ok ? 0u : 2048u;
@@ -329,13 +341,19 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
         // everything below the map is 0 or "negative" (a huge unsigned), everything above is > span + 1: one unsigned
         // minimum per axis lands all of it on a border cell
         const unsigned bi = min(ci, span_x + 2u), bj = min(cj, span_y + 2u);
-        col = (bi << 3) + (__umul24(bj & ~7u, M.dense_k) + bj);
+        // 8 bi + bj + dense_k (bj & ~7) as shift-add, and, multiply-add: stated, because the compiler splits the
+        // multiply-add into v_mul_u32_u24 + v_add3_u32 with the shift on its own (one operation more per evaluation)
+        const unsigned t = (bi << 3) + bj, bh = bj & ~7u;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(col) : "v"(bh), "s"(M.dense_k), "v"(t));
         return 0u;
       }
       const unsigned xi = clamp_1_to(ci, span_x + 1u), xj = clamp_1_to(cj, span_y + 1u);
       const bool ok = xi == ci && xj == cj;
       if (DENSE)
-        col = (xi << 3) + (__umul24(xj & ~7u, M.dense_k) + xj);
+      {
+        const unsigned t = (xi << 3) + xj, xh = xj & ~7u;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(col) : "v"(xh), "s"(M.dense_k), "v"(t));
+      }
       else
         col = __umul24(xj, width4) + (xi << 2);
       return ok ? 0u : 2048u;
@@ -387,7 +405,7 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
           bad[2 * h + 1] = cell(wx.y, wy.y, wz.y, col[2 * h + 1], ck[2 * h + 1]);
         }
       }
-      if (g == n_groups - 1 && np != np_pad)
+      if (!BORDER && g == n_groups - 1 && np != np_pad)
       {
         // the padding lanes of the chunk's last group evaluate a harmless point and add the table's zero
 #pragma unroll
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(256, 6) void k_cloud_score(const CloudScoreArgs A)
         lvl[u] = DENSE ? st[u] : (unsigned)ratio_b[st[u] + ck[u]];
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        acc += *reinterpret_cast<const double*>(table_b + max(lvl[u] << 3, bd[u]));
+        acc += *reinterpret_cast<const double*>(table_b + (BORDER ? lvl[u] << 3 : max(lvl[u] << 3, bd[u])));
     };
     stage1(0, start_a, ck_a, bad_a);
     for (int g = 0; g < n_groups; g += 2)
