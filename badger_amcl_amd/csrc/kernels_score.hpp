@@ -584,7 +584,9 @@ struct BeamRec
 // most kIntDivRayCells cells -- the host picks the variant per launch from range_max / resolution.
 constexpr int kIntDivRayCells = 1000;
 
-template <bool INT_DIV>
+// UNIFORM_START: (x0, y0) is the same for every lane of the wave (k_score_beam: wave = particle, read by v_readlane), so
+// the start cell's offset can be the multiply-add's scalar addend.
+template <bool INT_DIV, bool UNIFORM_START = false>
 __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y0, int x1, int y1, double range_max,
                                                   unsigned long long& walked)
 {
@@ -643,7 +645,15 @@ __device__ __forceinline__ double calc_range_skip(const MapDev& M, int x0, int y
       m = (int)__umulhi((unsigned)(__mul24(j, two_dmin) + dmaj), magic);
     else
       m = (int)fma((double)(__mul24(j, two_dmin) + dmaj), inv2d, 1e-6);
-    const unsigned off = (unsigned)(__mul24(j, step_major) + __mul24(m, step_minor) + base);
+    // base + j * step_major + m * step_minor as the two multiply-adds it is: written with __mul24 and additions the
+    // compiler issues two multiplies and a three-operand add (one operation more per look-up of a ~10-operation trip)
+    int t1, off_i;
+    if (UNIFORM_START)
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(j), "v"(step_major), "s"(__builtin_amdgcn_readfirstlane(base)));
+    else
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(j), "v"(step_major), "v"(base));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(off_i) : "v"(m), "v"(step_minor), "v"(t1));
+    const unsigned off = (unsigned)off_i;
     const int d = (int)((*reinterpret_cast<const uint32_t*>(cheb + off) >> qshift) & 255u);
     hit = d == 0;
     if (hit || j >= last)  // (this shape compiles to one block; testing d after the loop does not)
@@ -735,7 +745,7 @@ __global__ __launch_bounds__(BLOCK) BPF_BEAM_WAVES_ATTR void k_score_beam(const 
         const double sa = s * B.cb + c * B.sb;
         const int x1 = world_to_cell_rcp(ox + A.range_max * ca, M.origin_x, M.resolution, A.inv_resolution, M.half_x);
         const int y1 = world_to_cell_rcp(oy + A.range_max * sa, M.origin_y, M.resolution, A.inv_resolution, M.half_y);
-        const double map_range = calc_range_skip<INT_DIV>(M, sx0, sy0, x1, y1, A.range_max, walked);
+        const double map_range = calc_range_skip<INT_DIV, true>(M, sx0, sy0, x1, y1, A.range_max, walked);
         const double z = B.obs - map_range;
         double pz = 0.0;
         pz += A.z_hit * exp(-(z * z) / A.denom);
