@@ -357,7 +357,12 @@ int bpf_pf_get_max_weight_pose(bpf_engine* e, double* max_weight, double pose[3]
 
 /* ------------------------------------------------------------------ 3-D map + point cloud
  * OctoMap LUT state (include/amcl/map/octomap.h:96-110): pose_indices_, distance_ratios_,
- * cropped_min_cells_, cropped_max_cells_, resolution_, max_distance_to_object_. */
+ * cropped_min_cells_, cropped_max_cells_, resolution_, max_distance_to_object_.
+ * Besides the two arrays the engine keeps a dense copy laid out for the scoring kernel's gathers when it fits 1 GiB;
+ * this call also reads distance_ratios once on the host to find two byte values no entry holds: they mark the dense
+ * copy's border cells (off the map) and one spare plane (a zero term), which is what lets the scoring kernel of a
+ * planar mounting do without its on-the-map comparisons.  A LUT that uses more than 254 distinct ratios keeps the
+ * comparisons; the weights are the same either way. */
 int bpf_map3d_set(bpf_engine* e, const uint32_t* pose_indices, size_t n_pose_indices,
                   const uint8_t* distance_ratios, size_t n_distance_ratios, const int min_cells[3],
                   const int max_cells[3], double resolution, double max_dist);
